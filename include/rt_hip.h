@@ -1,0 +1,147 @@
+/* rt_hip.h - C-ABI of the MI355X rendering core (librt_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of dw-evans/raytracer: what the
+ * reference does between `RayTracerDynamic.configure_buffers_and_uniforms`
+ * (scripts/application.py:919-1002) and the per-pass `vao.render` that runs
+ * shaders/raytracer.fs.glsl (scripts/application.py:1052-1058), plus the numba scene-prep
+ * it calls on the way (scripts/numba_utils/classes.py:254-257, 315-342;
+ * scripts/scenes/chunker.py:94-106).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative RT_E_* code on failure; the text of
+ *    the last failure of a context is `rt_last_error(ctx)`;
+ *  - host buffers are caller-owned and copied during the call; the context owns its
+ *    device memory; one context per GPU per host thread, calls are not re-entrant;
+ *  - images are W*H*3 float32, row 0 = BOTTOM scanline (what `fbo.read` returns in the
+ *    reference, application.py:1104-1107);
+ *  - all arithmetic on the path is IEEE binary32 in the expression order written down in
+ *    DESIGN.md ("arithmetic contract"), so results are bit-identical to oracle/rt_oracle.c.
+ *
+ * The CPU oracle (oracle/librt_oracle.so) exports the same symbols so that the test
+ * harness can drive both through one binding; the product never loads it.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum {
+    RT_OK = 0,
+    RT_E_ARG = -1,     /* bad argument (null pointer, negative size, index out of range) */
+    RT_E_STATE = -2,   /* call order: no scene / no camera / no image size yet            */
+    RT_E_DEVICE = -3,  /* HIP runtime error (text in rt_last_error)                        */
+    RT_E_LIMIT = -4,   /* scene exceeds a stated limit (BVH depth > RT_MAX_STACK-1 ...)    */
+    RT_E_NOMEM = -5
+};
+
+/* rt_render flags */
+enum {
+    RT_ACCUM_MEAN = 0, /* reference running mean: c = c*(1-1/p) + L*(1/p), p = pass index
+                          (raytracer.fs.glsl:1013-1025); needs pass_stride == 1            */
+    RT_ACCUM_SUM = 1   /* c += L  (spp-sharding across GPUs; combine with an all-reduce)   */
+};
+
+#define RT_MAX_STACK 32 /* traversal stack entries; reference uses 16 (raytracer.fs.glsl:553)
+                           but its builder allows depth 20 (chunker.py:24) -> needs 21      */
+
+/* Work counters of the render/first-hit launches since the last rt_reset_stats.
+ * ray = one closest-hit query = one calculateRayCollision (raytracer.fs.glsl:518-641). */
+typedef struct rt_stats_t {
+    uint64_t rays;        /* closest-hit queries issued                                   */
+    uint64_t box_tests;   /* boundingBoxIntersect evaluations  (B)                        */
+    uint64_t tri_tests;   /* rayTriangle evaluations           (T)                        */
+    uint64_t shaded_hits; /* hits that reached the material code (H)                      */
+    uint64_t samples;     /* camera samples started (pixels * rays_per_pixel * passes)    */
+    double kernel_ms;     /* device time of those launches (hipEvent), 0 for the oracle   */
+    uint64_t launches;
+} rt_stats_t;
+
+/* replaces: ProgramABC.__init__/initialise creating the GL context (application.py:499-575) */
+int rt_create(int device, rt_ctx** out);
+int rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx);
+/* "hip" for librt_hip.so, "oracle" for the CPU oracle */
+const char* rt_backend_name(void);
+
+/* replaces: the buffer uploads of configure_buffers_and_uniforms (application.py:924-987):
+ *   tris28        N x 28 float32 std140 `Triangle` image  (SSBO 9,  raytracer.fs.glsl:93-110)
+ *   meshes128     128-byte std140 `Mesh` records          (UBO 10,  :186-198)
+ *   nodes48       48-byte std140 `GraphNode` records      (SSBO 12, :136-149)
+ *   leaf_tri_ids  flat int32 leaf triangle-id list        (SSBO 13, :151-153)
+ *   spheres96     96-byte std140 `Sphere` records         (UBO 1,   :80-91), may be NULL/0
+ *   atmosphere80  one 80-byte `Material`                  (UBO 11,  :53-74)
+ * Triangle positions given here are the REST pose of every mesh when poses are later
+ * applied with rt_update_mesh_pose, or final world positions if that is never called.
+ * The library re-lays the data out (DESIGN.md "data layout in HBM"), validates every index
+ * and the BVH depth, and refits all node boxes from the triangles. */
+int rt_set_scene(rt_ctx* ctx, const float* tris28, int n_tris, const void* meshes128, int n_meshes,
+                 const void* nodes48, int n_nodes, const int32_t* leaf_tri_ids, int n_ids,
+                 const void* spheres96, int n_spheres, const void* atmosphere80);
+
+/* replaces: re-upload of UBO 10/11 each frame for animated materials (application.py:964-976) */
+int rt_set_materials(rt_ctx* ctx, const void* meshes128, int n_meshes, const void* atmosphere80);
+
+/* replaces: numba update_triangles_to_csys (numba_utils/classes.py:195-224, 254-257) +
+ * chunker refit (chunker.py:94-106, 197-214) + triangles_to_array re-pack (:315-342) for one
+ * mesh, on the device.  T16 = row-major float32 4x4, rotation in [0:3,0:3], translation in
+ * ROW 3 (row-vector convention, numba_utils/classes.py:44-48). */
+int rt_update_mesh_transform(rt_ctx* ctx, int mesh, const float T16[16]);
+/* same, from pos (x,y,z) + quaternion (x,y,z,w) with the dtype rules of
+ * numba_utils/functions.py:35-88 applied on the host side of the library */
+int rt_update_mesh_pose(rt_ctx* ctx, int mesh, const float pos[3], const float quat[4]);
+/* read back the posed std140 triangle image / node image (tests, picking) */
+int rt_read_tris28(rt_ctx* ctx, float* out_tris28);
+int rt_read_nodes48(rt_ctx* ctx, void* out_nodes48);
+
+/* replaces: the camera uniform writes of calculate_frame (application.py:1175-1180):
+ * ViewParams, CamLocalToWorldMatrix (numpy row-major float32 bytes), CamGlobalPos,
+ * depthOfFieldStrength, antialiasStrength */
+int rt_set_camera(rt_ctx* ctx, const float view_params[3], const float local_to_world16[16],
+                  const float cam_pos[3], float dof, float aa);
+
+/* replaces: texA/texB creation (application.py:893-900); clears the accumulator */
+int rt_resize(rt_ctx* ctx, int width, int height);
+int rt_reset_accum(rt_ctx* ctx);
+/* render into caller-provided DEVICE memory (W*H*3 float32, e.g. a torch tensor that a
+ * later all-reduce works on); NULL returns to the internal buffer.  Oracle: host memory. */
+int rt_bind_accum(rt_ctx* ctx, void* device_ptr);
+
+/* replaces: render_with_chunk's pass loop (application.py:1190-1207): passes
+ * first_pass, first_pass+stride, ... (n_passes of them) are the `frameNumber` values that
+ * seed the per-pixel RNG (raytracer.fs.glsl:956-957); rays_per_pixel / max_bounces are the
+ * RAYS_PER_PIXEL / MAX_BOUNCES uniforms (application.py:1182-1183). */
+int rt_render(rt_ctx* ctx, uint32_t first_pass, uint32_t n_passes, uint32_t pass_stride,
+              int rays_per_pixel, int max_bounces, int flags);
+
+/* primary ray of sample 0 of `pass` per pixel: closest triangle id (-1 = miss; spheres
+ * report -2-sphere_index) and distance (1e20 on a miss).  No reference counterpart: this is
+ * the first-hit parity probe BASELINE.json asks for. */
+int rt_first_hit(rt_ctx* ctx, uint32_t pass, int32_t* tri_id_out, float* t_out);
+
+/* replaces: fbo.read (application.py:1104).  rt_read_accum copies the raw accumulator;
+ * rt_read_mean divides a SUM accumulator by the passes accumulated (identity in MEAN mode) */
+int rt_read_accum(rt_ctx* ctx, float* out_whc, uint64_t* n_passes_out);
+int rt_read_mean(rt_ctx* ctx, float* out_whc);
+/* tell the context how many passes an externally combined (all-reduced) SUM now holds */
+int rt_set_accum_passes(rt_ctx* ctx, uint64_t n_passes);
+
+/* counters: enable => launches use the counting kernel variant (slower; not for timing) */
+int rt_enable_stats(rt_ctx* ctx, int enable);
+int rt_reset_stats(rt_ctx* ctx);
+int rt_get_stats(rt_ctx* ctx, rt_stats_t* out);
+
+/* block until all work of the context is done (hipStreamSynchronize) */
+int rt_sync(rt_ctx* ctx);
+/* the hipStream_t the context launches on, as an opaque pointer (for event timing) */
+void* rt_stream(rt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

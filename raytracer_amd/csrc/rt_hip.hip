@@ -1,0 +1,878 @@
+// rt_hip.hip - kernels and C-ABI of librt_hip.so (gfx950 / MI355X only).
+//
+// Kernels
+//   k_pose        device twin of numba update_triangles_to_csys + triangles_to_array
+//                 (scripts/numba_utils/classes.py:195-224, 315-342): rest pose -> world pose,
+//                 plus the per-triangle plane constants the intersection test needs
+//   k_refit_level device twin of the chunker refit (scripts/scenes/chunker.py:197-214),
+//                 bottom-up by tree level (exact: min/max are associative)
+//   k_pack_nodes  copies refreshed child boxes into the 64-byte traversal records
+//   k_render      ray generation + traversal + bounce loop + accumulation
+//                 (shaders/raytracer.fs.glsl main() :928-1044)
+//   k_first_hit   primary-ray closest hit only (parity probe)
+//   k_gather_*    read-back of posed triangles / refit boxes in the reference's std140 order
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.py).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "rt_dev_trace.h"
+
+// ----------------------------------------------------------------------------------------
+// device kernels
+// ----------------------------------------------------------------------------------------
+struct PoseArgs {
+    const float4* rest;      // 6 x float4 per slot: A, B, C, nA, nB, nC (rest pose)
+    const int* slot_mesh;    // mesh of each slot
+    const int* slot_rem;     // triangles left in the leaf after this one
+    const int* slot_id;      // triId of each slot
+    const float* xf;         // 16 floats per mesh, row-major, translation in row 3
+    const unsigned char* dirty;  // per mesh: 1 = re-pose (0 = leave), 2 = copy rest (no transform yet)
+    float4* geo;
+    float4* nrm;
+    int n_slots;
+};
+
+__global__ __launch_bounds__(256) void k_pose(PoseArgs a) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n_slots) return;
+    int mesh = a.slot_mesh[k];
+    unsigned char mode = a.dirty[mesh];
+    if (mode == 0) return;
+    const float4* r = a.rest + 6 * (size_t)k;
+    float p[3][3], n[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float4 pv = r[c], nv = r[3 + c];
+        if (mode == 2) {
+            p[c][0] = pv.x; p[c][1] = pv.y; p[c][2] = pv.z;
+            n[c][0] = nv.x; n[c][1] = nv.y; n[c][2] = nv.z;
+        } else {
+            const float* T = a.xf + 16 * (size_t)mesh;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                // [p,1] . T, k-ordered float32 sum, no fma (DESIGN.md arithmetic contract)
+                p[c][j] = ((pv.x * T[0 + j] + pv.y * T[4 + j]) + pv.z * T[8 + j]) + T[12 + j];
+                n[c][j] = (nv.x * T[0 + j] + nv.y * T[4 + j]) + nv.z * T[8 + j];
+            }
+        }
+    }
+    v3 A = V3(p[0][0], p[0][1], p[0][2]), B = V3(p[1][0], p[1][1], p[1][2]), C = V3(p[2][0], p[2][1], p[2][2]);
+    v3 N = cross3(B - A, C - A);                 // raytracer.fs.glsl:316-319
+    float d = -dot3(N, A);                       // :345
+    float4* g = a.geo + 4 * (size_t)k;
+    g[0] = make_float4(A.x, A.y, A.z, N.x);
+    g[1] = make_float4(B.x, B.y, B.z, N.y);
+    g[2] = make_float4(C.x, C.y, C.z, N.z);
+    g[3] = make_float4(d, __int_as_float(a.slot_rem[k]), __int_as_float(a.slot_id[k]), 0.0f);
+    float4* o = a.nrm + 3 * (size_t)k;
+    o[0] = make_float4(n[0][0], n[0][1], n[0][2], __int_as_float(mesh));
+    o[1] = make_float4(n[1][0], n[1][1], n[1][2], 0.0f);
+    o[2] = make_float4(n[2][0], n[2][1], n[2][2], 0.0f);
+}
+
+// visited-node table: c1/c2 = child visit indices (-1 none); leaves: [start, start+count) slots
+struct VNode { int c1, c2, start, count; };
+
+__global__ __launch_bounds__(256) void k_refit_level(const VNode* vn, const int* level_nodes, int n, const float4* geo, float4* nbox) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int v = level_nodes[i];
+    VNode nd = vn[v];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (nd.c1 < 0 && nd.c2 < 0) {
+        for (int k = nd.start; k < nd.start + nd.count; k++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float4 p = geo[4 * (size_t)k + c];
+                lo[0] = p.x < lo[0] ? p.x : lo[0]; hi[0] = p.x > hi[0] ? p.x : hi[0];
+                lo[1] = p.y < lo[1] ? p.y : lo[1]; hi[1] = p.y > hi[1] ? p.y : hi[1];
+                lo[2] = p.z < lo[2] ? p.z : lo[2]; hi[2] = p.z > hi[2] ? p.z : hi[2];
+            }
+        }
+    } else {
+        int ch[2] = {nd.c1, nd.c2};
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (ch[s] < 0) continue;
+            float4 a = nbox[2 * (size_t)ch[s]], b = nbox[2 * (size_t)ch[s] + 1];
+            lo[0] = a.x < lo[0] ? a.x : lo[0]; hi[0] = b.x > hi[0] ? b.x : hi[0];
+            lo[1] = a.y < lo[1] ? a.y : lo[1]; hi[1] = b.y > hi[1] ? b.y : hi[1];
+            lo[2] = a.z < lo[2] ? a.z : lo[2]; hi[2] = b.z > hi[2] ? b.z : hi[2];
+        }
+    }
+    nbox[2 * (size_t)v] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    nbox[2 * (size_t)v + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+}
+
+// interior record r <- boxes of its children; PackInfo is static topology
+struct PackInfo { int c1, c2, ref1, ref2; };
+
+__global__ __launch_bounds__(256) void k_pack_nodes(const PackInfo* pi, int n_rec, const float4* nbox, float4* nodes,
+                                                    const int* root_v, const int* root_ref, int n_meshes, float4* roots) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rec) {
+        PackInfo p = pi[i];
+        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 lo1 = p.c1 >= 0 ? nbox[2 * (size_t)p.c1] : z, hi1 = p.c1 >= 0 ? nbox[2 * (size_t)p.c1 + 1] : z;
+        float4 lo2 = p.c2 >= 0 ? nbox[2 * (size_t)p.c2] : z, hi2 = p.c2 >= 0 ? nbox[2 * (size_t)p.c2 + 1] : z;
+        lo1.w = __int_as_float(p.ref1);
+        hi1.w = __int_as_float(p.ref2);
+        float4* o = nodes + 4 * (size_t)i;
+        o[0] = lo1; o[1] = hi1; o[2] = lo2; o[3] = hi2;
+    }
+    if (i < n_meshes) {
+        float4 lo = nbox[2 * (size_t)root_v[i]], hi = nbox[2 * (size_t)root_v[i] + 1];
+        lo.w = __int_as_float(root_ref[i]);
+        roots[2 * i] = lo;
+        roots[2 * i + 1] = hi;
+    }
+}
+
+// std140 read-back helpers
+__global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const float4* nrm, int n_slots, float* out28, int n_tris) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_slots) return;
+    float4 g0 = geo[4 * (size_t)k], g1 = geo[4 * (size_t)k + 1], g2 = geo[4 * (size_t)k + 2], g3 = geo[4 * (size_t)k + 3];
+    float4 a = nrm[3 * (size_t)k], b = nrm[3 * (size_t)k + 1], c = nrm[3 * (size_t)k + 2];
+    int id = __float_as_int(g3.z);
+    if (id < 0 || id >= n_tris) return;
+    float* o = out28 + 28 * (size_t)id;
+    o[0] = g0.x; o[1] = g0.y; o[2] = g0.z; o[4] = g1.x; o[5] = g1.y; o[6] = g1.z; o[8] = g2.x; o[9] = g2.y; o[10] = g2.z;
+    o[12] = a.x; o[13] = a.y; o[14] = a.z; o[16] = b.x; o[17] = b.y; o[18] = b.z; o[20] = c.x; o[21] = c.y; o[22] = c.z;
+}
+
+__device__ __forceinline__ void flush_counters(const Counters& c, unsigned long long* out) {
+    // per-wave reduction, then one atomic per wave and counter
+    unsigned long long v[4] = {c.rays, c.box, c.tri, c.hits};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        unsigned long long x = v[q];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(out + q, x);
+    }
+}
+
+struct RenderArgs {
+    DevScene scene;
+    DevCamera cam;
+    MatDev atmo;
+    float* accum;                 // W*H*3
+    unsigned long long* counters; // 4
+    uint32_t first_pass, n_passes, pass_stride;
+    int rays_per_pixel, max_bounces, sum_mode;
+};
+
+// One lane per pixel; a wave covers an 8x8 pixel tile, a block a 16x16 tile, so the primary
+// rays of a wave are coherent.  All passes of the launch are looped in-kernel: the pixel's
+// accumulator is read once and written once per launch.
+template <bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_render(RenderArgs a) {
+    __shared__ int s_stack[RT_STACK * RT_BLOCK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    Counters cnt = {0, 0, 0, 0};
+    const bool live = px < a.cam.width && py < a.cam.height;
+    if (live) {
+        int* stack = s_stack + threadIdx.x;
+        const v3 view_point = view_point_of(a.cam, px, py);
+        float* acc = a.accum + ((size_t)py * a.cam.width + px) * 3;
+        v3 col = V3(acc[0], acc[1], acc[2]);
+        const uint32_t px_id = (uint32_t)py * (uint32_t)a.cam.width + (uint32_t)px;
+        for (uint32_t p = 0; p < a.n_passes; p++) {
+            const uint32_t pass = a.first_pass + p * a.pass_stride;
+            uint32_t rng = px_id + pass * 747796405u;          // :956-957
+            v3 total = V3(0.0f, 0.0f, 0.0f);
+            for (int s = 0; s < a.rays_per_pixel; s++) {
+                PathState ray;
+                new_sample_ray(a.cam, a.atmo, view_point, rng, ray);
+                total = total + trace_path<STATS>(a.scene, a.atmo, ray, rng, a.max_bounces, stack, cnt);
+            }
+            const float rpp = (float)a.rays_per_pixel;
+            total = V3(total.x / rpp, total.y / rpp, total.z / rpp);   // :1008
+            if (a.sum_mode) {
+                col = col + total;
+            } else {                                                   // running mean :1015-1021
+                const float w = 1.0f / (float)pass, om = 1.0f - w;
+                col = V3(col.x * om + total.x * w, col.y * om + total.y * w, col.z * om + total.z * w);
+            }
+        }
+        acc[0] = col.x; acc[1] = col.y; acc[2] = col.z;
+    }
+    if (STATS) flush_counters(cnt, a.counters);
+}
+
+struct FirstHitArgs {
+    DevScene scene;
+    DevCamera cam;
+    MatDev atmo;
+    int32_t* ids;
+    float* ts;
+    unsigned long long* counters;
+    uint32_t pass;
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_first_hit(FirstHitArgs a) {
+    __shared__ int s_stack[RT_STACK * RT_BLOCK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    Counters cnt = {0, 0, 0, 0};
+    if (px < a.cam.width && py < a.cam.height) {
+        uint32_t rng = (uint32_t)py * (uint32_t)a.cam.width + (uint32_t)px + a.pass * 747796405u;
+        PathState ray;
+        new_sample_ray(a.cam, a.atmo, view_point_of(a.cam, px, py), rng, ray);
+        Hit h = closest_hit<STATS>(a.scene, ray.origin, ray.dir, -1, -1, false, s_stack + threadIdx.x, cnt);
+        int id = -1;
+        if (h.rank != 0x7fffffff) {
+            if (h.rank < 0) id = -2 - (h.rank - RT_SPHERE_RANK);
+            else id = __float_as_int(a.scene.tri_geo[4 * (size_t)h.rank + 3].z);
+        }
+        size_t o = (size_t)py * a.cam.width + px;
+        a.ids[o] = id;
+        a.ts[o] = h.t;
+    }
+    if (STATS) flush_counters(cnt, a.counters);
+}
+
+// ----------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------
+namespace {
+
+struct Std140Tri { float posA[3], _a, posB[3], _b, posC[3], _c, nA[3], _d, nB[3], _e, nC[3]; int32_t meshIndex, triId, _f[3]; };
+struct Std140Mesh { int32_t index, node0Id, _p[2]; float bboxMin[4], bboxMax[4]; MatDev material; };
+struct Std140Node { float aabbMin[3], _p, aabbMax[3]; int32_t id, c1, c2, off, cnt; };
+static_assert(sizeof(Std140Tri) == 112 && sizeof(Std140Mesh) == 128 && sizeof(Std140Node) == 48, "std140 sizes");
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (!count) return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    // scene (device)
+    DevBuf<float4> rest, geo, nrm, nodes, roots, nbox;
+    DevBuf<int> slot_mesh, slot_rem, slot_id, level_nodes, root_v, root_ref;
+    DevBuf<float> xf;
+    DevBuf<unsigned char> dirty;
+    DevBuf<VNode> vnodes;
+    DevBuf<PackInfo> pack;
+    DevBuf<MatDev> mats;
+    DevBuf<SphereDev> spheres;
+    DevBuf<unsigned long long> counters;
+    // scene (host mirrors)
+    std::vector<float> h_xf;
+    std::vector<unsigned char> h_dirty;
+    std::vector<int> level_off;           // level l covers level_nodes[level_off[l] .. level_off[l+1])
+    std::vector<int> node_first_visit;    // original node id -> visit index (-1 if unreachable)
+    std::vector<Std140Node> h_nodes;      // topology as uploaded (for rt_read_nodes48)
+    MatDev atmo{};
+    int n_tris = 0, n_slots = 0, n_meshes = 0, n_nodes = 0, n_visit = 0, n_rec = 0, n_spheres = 0;
+    bool have_scene = false, have_cam = false, prep_pending = false;
+    // camera / image
+    DevCamera cam{};
+    DevBuf<float> accum_own;
+    float* accum = nullptr;
+    uint64_t n_accum = 0;
+    bool sum_mode = false;
+    // stats
+    bool stats_on = false;
+    rt_stats_t st{};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+};
+
+namespace {
+
+int fail(rt_ctx* c, int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCK(c, call)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) return fail((c), RT_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int upload(rt_ctx* c, DevBuf<T>& b, const std::vector<T>& v) {
+    HIPCK(c, b.alloc(v.size()));
+    if (!v.empty()) HIPCK(c, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return RT_OK;
+}
+
+inline unsigned blocks_for(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// numba dtype rules of mat33_create_from_quaternion (scripts/numba_utils/functions.py:35-82)
+void pose_matrix(const float pos[3], const float q_in[4], float T[16]) {
+    float q[4] = {q_in[0], q_in[1], q_in[2], q_in[3]};
+    float nn = std::sqrt(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]);
+    if (!(std::fabs((double)nn - 1.0) <= 1e-8 + 1e-5))
+        for (int i = 0; i < 4; i++) q[i] = q[i] / nn;
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    float xx = x * x, yy = y * y, zz = z * z, ww = w * w;
+    float xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+    double inv = 1.0 / (double)(((xx + yy) + zz) + ww);
+    std::memset(T, 0, 64);
+    T[0] = (float)((double)(((xx - yy) - zz) + ww) * inv);
+    T[5] = (float)((double)(((-xx + yy) - zz) + ww) * inv);
+    T[10] = (float)((double)(((-xx - yy) + zz) + ww) * inv);
+    T[4] = (float)(2.0 * (double)(xy + zw) * inv);
+    T[1] = (float)(2.0 * (double)(xy - zw) * inv);
+    T[8] = (float)(2.0 * (double)(xz - yw) * inv);
+    T[2] = (float)(2.0 * (double)(xz + yw) * inv);
+    T[9] = (float)(2.0 * (double)(yz + xw) * inv);
+    T[6] = (float)(2.0 * (double)(yz - xw) * inv);
+    T[12] = pos[0]; T[13] = pos[1]; T[14] = pos[2]; T[15] = 1.0f;
+}
+
+// pose dirty meshes, refit every level bottom-up, re-pack the traversal records
+int run_prep(rt_ctx* c) {
+    if (!c->prep_pending) return RT_OK;
+    HIPCK(c, hipMemcpyAsync(c->xf.p, c->h_xf.data(), c->h_xf.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->dirty.p, c->h_dirty.data(), c->h_dirty.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));   // pageable sources: h_dirty is cleared below
+    if (c->n_slots) {
+        PoseArgs pa{c->rest.p, c->slot_mesh.p, c->slot_rem.p, c->slot_id.p, c->xf.p, c->dirty.p, c->geo.p, c->nrm.p, c->n_slots};
+        hipLaunchKernelGGL(k_pose, dim3(blocks_for(c->n_slots)), dim3(256), 0, c->stream, pa);
+    }
+    for (int l = (int)c->level_off.size() - 2; l >= 0; l--) {
+        int n = c->level_off[l + 1] - c->level_off[l];
+        if (n <= 0) continue;
+        hipLaunchKernelGGL(k_refit_level, dim3(blocks_for(n)), dim3(256), 0, c->stream, c->vnodes.p,
+                           c->level_nodes.p + c->level_off[l], n, c->geo.p, c->nbox.p);
+    }
+    size_t m = (size_t)std::max(c->n_rec, c->n_meshes);
+    if (m)
+        hipLaunchKernelGGL(k_pack_nodes, dim3(blocks_for(m)), dim3(256), 0, c->stream, c->pack.p, c->n_rec, c->nbox.p,
+                           c->nodes.p, c->root_v.p, c->root_ref.p, c->n_meshes, c->roots.p);
+    HIPCK(c, hipGetLastError());
+    for (auto& d : c->h_dirty) d = 0;
+    c->prep_pending = false;
+    return RT_OK;
+}
+
+DevScene scene_view(const rt_ctx* c) {
+    DevScene s;
+    s.tri_geo = c->geo.p; s.tri_nrm = c->nrm.p; s.nodes = c->nodes.p; s.roots = c->roots.p;
+    s.mats = c->mats.p; s.spheres = c->spheres.p; s.n_meshes = c->n_meshes; s.n_spheres = c->n_spheres;
+    return s;
+}
+
+int check_ready(rt_ctx* c) {
+    if (!c->have_scene) return fail(c, RT_E_STATE, "no scene");
+    if (!c->have_cam) return fail(c, RT_E_STATE, "no camera");
+    if (!c->accum) return fail(c, RT_E_STATE, "no image size");
+    return RT_OK;
+}
+
+int resolve_events(rt_ctx* c) {
+    if (c->pending_events.empty()) return RT_OK;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    for (auto& ev : c->pending_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) c->st.kernel_ms += ms;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    c->pending_events.clear();
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_backend_name(void) { return "hip"; }
+const char* rt_last_error(const rt_ctx* c) { return c ? c->err : "null context"; }
+
+int rt_create(int device, rt_ctx** out) {
+    if (!out) return RT_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return RT_E_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return RT_E_DEVICE;
+    rt_ctx* c = new (std::nothrow) rt_ctx();
+    if (!c) return RT_E_NOMEM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
+    if (c->counters.alloc(4) != hipSuccess || hipMemsetAsync(c->counters.p, 0, 32, c->stream) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return RT_E_DEVICE;
+    }
+    *out = c;
+    return RT_OK;
+}
+
+static void free_scene(rt_ctx* c) {
+    c->rest.release(); c->geo.release(); c->nrm.release(); c->nodes.release(); c->roots.release(); c->nbox.release();
+    c->slot_mesh.release(); c->slot_rem.release(); c->slot_id.release(); c->level_nodes.release();
+    c->root_v.release(); c->root_ref.release(); c->xf.release(); c->dirty.release(); c->vnodes.release();
+    c->pack.release(); c->mats.release(); c->spheres.release();
+    c->have_scene = false;
+}
+
+int rt_destroy(rt_ctx* c) {
+    if (!c) return RT_E_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& ev : c->pending_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    free_scene(c);
+    c->accum_own.release();
+    c->counters.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes128, int n_meshes, const void* nodes48,
+                 int n_nodes, const int32_t* leaf_ids, int n_ids, const void* spheres96, int n_spheres,
+                 const void* atmosphere80) {
+    if (!c) return RT_E_ARG;
+    if (n_tris < 0 || n_meshes < 0 || n_nodes < 0 || n_ids < 0 || n_spheres < 0) return fail(c, RT_E_ARG, "negative count");
+    if ((n_tris && !tris28) || (n_meshes && !meshes128) || (n_nodes && !nodes48) || (n_ids && !leaf_ids) ||
+        (n_spheres && !spheres96) || !atmosphere80)
+        return fail(c, RT_E_ARG, "null buffer with non-zero count");
+    if (n_meshes > 256 || n_spheres > 256) return fail(c, RT_E_LIMIT, "more than 256 meshes/spheres");
+    HIPCK(c, hipSetDevice(c->device));
+    const Std140Tri* tris = (const Std140Tri*)tris28;
+    const Std140Mesh* meshes = (const Std140Mesh*)meshes128;
+    const Std140Node* nodes = (const Std140Node*)nodes48;
+
+    // ---- validation (same rules as the oracle) ----
+    for (int i = 0; i < n_ids; i++)
+        if (leaf_ids[i] < 0 || leaf_ids[i] >= n_tris) return fail(c, RT_E_ARG, "leaf_tri_ids[%d] out of range", i);
+    for (int i = 0; i < n_tris; i++) {
+        if (tris[i].meshIndex < 0 || tris[i].meshIndex >= n_meshes) return fail(c, RT_E_ARG, "triangle %d: bad mesh index", i);
+        if (tris[i].triId != i) return fail(c, RT_E_ARG, "triangle %d: triId != index (scenes/utils.py:18-25)", i);
+    }
+    for (int i = 0; i < n_nodes; i++) {
+        const Std140Node& n = nodes[i];
+        if (n.c1 >= n_nodes || n.c2 >= n_nodes) return fail(c, RT_E_ARG, "node %d: child out of range", i);
+        if ((n.c1 >= 0 && n.c1 <= i) || (n.c2 >= 0 && n.c2 <= i)) return fail(c, RT_E_ARG, "node %d: child id not greater than parent id", i);
+        if (n.c1 < 0 && n.c2 < 0)
+            if (n.cnt < 0 || n.off < 0 || (int64_t)n.off + n.cnt > n_ids) return fail(c, RT_E_ARG, "leaf node %d: triangle range out of bounds", i);
+    }
+    for (int j = 0; j < n_meshes; j++)
+        if (meshes[j].node0Id < 0 || meshes[j].node0Id >= n_nodes) return fail(c, RT_E_ARG, "mesh %d: bad root node", j);
+
+    // ---- traversal-order walk: mesh ascending, depth first, second child first ----
+    struct Visit { int node, depth, parent_rec, which; };
+    std::vector<VNode> vnodes;
+    std::vector<int> vdepth, vnode_id;
+    std::vector<PackInfo> pack;
+    std::vector<int> root_v(n_meshes), root_ref(n_meshes);
+    std::vector<float4> rest;
+    std::vector<int> slot_mesh, slot_rem, slot_id;
+    std::vector<int> first_visit(n_nodes, -1);
+    const size_t visit_cap = 4 * (size_t)n_nodes + 16;
+    int max_depth = 0;
+    for (int j = 0; j < n_meshes; j++) {
+        std::vector<Visit> st;
+        st.push_back({meshes[j].node0Id, 0, -1, 0});
+        while (!st.empty()) {
+            Visit cur = st.back();
+            st.pop_back();
+            if (vnodes.size() >= visit_cap) return fail(c, RT_E_LIMIT, "BVH is not a tree (shared sub-graphs blow up)");
+            const Std140Node& n = nodes[cur.node];
+            int v = (int)vnodes.size();
+            vnodes.push_back({-1, -1, 0, 0});
+            vdepth.push_back(cur.depth);
+            vnode_id.push_back(cur.node);
+            if (first_visit[cur.node] < 0) first_visit[cur.node] = v;
+            if (cur.depth > max_depth) max_depth = cur.depth;
+            if (cur.depth + 1 > RT_MAX_STACK) return fail(c, RT_E_LIMIT, "mesh %d: BVH deeper than %d", j, RT_MAX_STACK - 1);
+            int ref;
+            const bool leaf = n.c1 < 0 && n.c2 < 0;
+            if (leaf) {
+                vnodes[v].start = (int)slot_id.size();
+                vnodes[v].count = n.cnt;
+                for (int i = 0; i < n.cnt; i++) {
+                    const Std140Tri& t = tris[leaf_ids[n.off + i]];
+                    if (t.meshIndex != j)
+                        return fail(c, RT_E_ARG, "triangle %d in the BVH of mesh %d belongs to mesh %d", t.triId, j, t.meshIndex);
+                    const float* src[6] = {t.posA, t.posB, t.posC, t.nA, t.nB, t.nC};
+                    for (int q = 0; q < 6; q++) rest.push_back(make_float4(src[q][0], src[q][1], src[q][2], 0.f));
+                    slot_mesh.push_back(j);
+                    slot_rem.push_back(n.cnt - 1 - i);
+                    slot_id.push_back(t.triId);
+                }
+                ref = n.cnt > 0 ? ~vnodes[v].start : RT_NONE;     // an empty leaf contributes nothing
+            } else {
+                ref = (int)pack.size();
+                pack.push_back({-1, -1, RT_NONE, RT_NONE});
+                // push first child first so that the second child is visited first
+                if (n.c1 >= 0) st.push_back({n.c1, cur.depth + 1, ref, 1});
+                if (n.c2 >= 0) st.push_back({n.c2, cur.depth + 1, ref, 2});
+            }
+            if (cur.parent_rec < 0) { root_v[j] = v; root_ref[j] = ref; }
+            else if (cur.which == 1) { pack[cur.parent_rec].c1 = v; pack[cur.parent_rec].ref1 = ref; }
+            else { pack[cur.parent_rec].c2 = v; pack[cur.parent_rec].ref2 = ref; }
+        }
+    }
+    // child visit indices for the refit (vnode.c1/c2), from the pack table
+    {
+        int rec = 0;
+        for (size_t v = 0; v < vnodes.size(); v++) {
+            const Std140Node& n = nodes[vnode_id[v]];
+            if (!(n.c1 < 0 && n.c2 < 0)) {
+                vnodes[v].c1 = pack[rec].c1;
+                vnodes[v].c2 = pack[rec].c2;
+                rec++;
+            }
+        }
+    }
+    // level lists (deepest first at refit time)
+    std::vector<int> level_off(max_depth + 2, 0), level_nodes(vnodes.size());
+    for (int d : vdepth) level_off[d + 1]++;
+    for (size_t l = 1; l < level_off.size(); l++) level_off[l] += level_off[l - 1];
+    {
+        std::vector<int> fill(level_off.begin(), level_off.end() - 1);
+        for (size_t v = 0; v < vnodes.size(); v++) level_nodes[fill[vdepth[v]]++] = (int)v;
+    }
+
+    // ---- upload ----
+    free_scene(c);
+    c->n_tris = n_tris; c->n_meshes = n_meshes; c->n_nodes = n_nodes; c->n_spheres = n_spheres;
+    c->n_slots = (int)slot_id.size(); c->n_visit = (int)vnodes.size(); c->n_rec = (int)pack.size();
+    int rc;
+    if ((rc = upload(c, c->rest, rest))) return rc;
+    if ((rc = upload(c, c->slot_mesh, slot_mesh))) return rc;
+    if ((rc = upload(c, c->slot_rem, slot_rem))) return rc;
+    if ((rc = upload(c, c->slot_id, slot_id))) return rc;
+    if ((rc = upload(c, c->vnodes, vnodes))) return rc;
+    if ((rc = upload(c, c->pack, pack))) return rc;
+    if ((rc = upload(c, c->level_nodes, level_nodes))) return rc;
+    if ((rc = upload(c, c->root_v, root_v))) return rc;
+    if ((rc = upload(c, c->root_ref, root_ref))) return rc;
+    std::vector<MatDev> mats(n_meshes);
+    for (int j = 0; j < n_meshes; j++) mats[j] = meshes[j].material;
+    if ((rc = upload(c, c->mats, mats))) return rc;
+    std::vector<SphereDev> sph(n_spheres);
+    if (n_spheres) std::memcpy(sph.data(), spheres96, (size_t)n_spheres * 96);
+    if ((rc = upload(c, c->spheres, sph))) return rc;
+    std::memcpy(&c->atmo, atmosphere80, 80);
+    HIPCK(c, c->geo.alloc(4 * (size_t)c->n_slots));
+    HIPCK(c, c->nrm.alloc(3 * (size_t)c->n_slots));
+    HIPCK(c, c->nodes.alloc(4 * (size_t)c->n_rec));
+    HIPCK(c, c->roots.alloc(2 * (size_t)n_meshes));
+    HIPCK(c, c->nbox.alloc(2 * (size_t)c->n_visit));
+    HIPCK(c, c->xf.alloc(16 * (size_t)std::max(n_meshes, 1)));
+    HIPCK(c, c->dirty.alloc((size_t)std::max(n_meshes, 1)));
+    c->h_xf.assign(16 * (size_t)std::max(n_meshes, 1), 0.f);
+    c->h_dirty.assign((size_t)std::max(n_meshes, 1), 2);        // 2 = copy rest pose as given
+    c->level_off = level_off;
+    c->node_first_visit = first_visit;
+    c->h_nodes.assign(nodes, nodes + n_nodes);
+    c->have_scene = true;
+    c->prep_pending = true;
+    // host staging vectors die at scope exit: make sure the async copies have been consumed
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return run_prep(c);
+}
+
+int rt_set_materials(rt_ctx* c, const void* meshes128, int n_meshes, const void* atmosphere80) {
+    if (!c) return RT_E_ARG;
+    if (!c->have_scene) return fail(c, RT_E_STATE, "no scene");
+    if (n_meshes != c->n_meshes || !meshes128) return fail(c, RT_E_ARG, "mesh count mismatch");
+    HIPCK(c, hipSetDevice(c->device));
+    const Std140Mesh* meshes = (const Std140Mesh*)meshes128;
+    std::vector<MatDev> mats(n_meshes);
+    for (int j = 0; j < n_meshes; j++) mats[j] = meshes[j].material;
+    if (n_meshes) HIPCK(c, hipMemcpyAsync(c->mats.p, mats.data(), (size_t)n_meshes * 80, hipMemcpyHostToDevice, c->stream));
+    if (atmosphere80) std::memcpy(&c->atmo, atmosphere80, 80);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_update_mesh_transform(rt_ctx* c, int mesh, const float T16[16]) {
+    if (!c || !T16) return RT_E_ARG;
+    if (!c->have_scene) return fail(c, RT_E_STATE, "no scene");
+    if (mesh < 0 || mesh >= c->n_meshes) return fail(c, RT_E_ARG, "mesh index out of range");
+    std::memcpy(&c->h_xf[16 * (size_t)mesh], T16, 64);
+    c->h_dirty[mesh] = 1;
+    c->prep_pending = true;      // batched: all dirty meshes are posed by one launch before the next use
+    return RT_OK;
+}
+
+int rt_update_mesh_pose(rt_ctx* c, int mesh, const float pos[3], const float quat[4]) {
+    if (!c || !pos || !quat) return RT_E_ARG;
+    float T[16];
+    pose_matrix(pos, quat, T);
+    return rt_update_mesh_transform(c, mesh, T);
+}
+
+int rt_read_tris28(rt_ctx* c, float* out) {
+    if (!c || !out) return RT_E_ARG;
+    if (!c->have_scene) return fail(c, RT_E_STATE, "no scene");
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = run_prep(c);
+    if (rc) return rc;
+    // static part (padding, mesh index, id) on the host, posed part gathered on the device
+    DevBuf<float> tmp;
+    HIPCK(c, tmp.alloc(28 * (size_t)std::max(c->n_tris, 1)));
+    HIPCK(c, hipMemsetAsync(tmp.p, 0, 28 * (size_t)std::max(c->n_tris, 1) * 4, c->stream));
+    if (c->n_slots)
+        hipLaunchKernelGGL(k_gather_tris28, dim3(blocks_for(c->n_slots)), dim3(256), 0, c->stream, c->geo.p, c->nrm.p,
+                           c->n_slots, tmp.p, c->n_tris);
+    hipError_t e = hipMemcpyAsync(out, tmp.p, 28 * (size_t)c->n_tris * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    tmp.release();
+    if (e != hipSuccess) return fail(c, RT_E_DEVICE, "read_tris28: %s", hipGetErrorString(e));
+    // ids and mesh indices: slot tables are authoritative
+    std::vector<int> sm(c->n_slots), si(c->n_slots);
+    if (c->n_slots) {
+        HIPCK(c, hipMemcpy(sm.data(), c->slot_mesh.p, (size_t)c->n_slots * 4, hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(si.data(), c->slot_id.p, (size_t)c->n_slots * 4, hipMemcpyDeviceToHost));
+    }
+    int32_t* oi = (int32_t*)out;
+    for (int i = 0; i < c->n_tris; i++) oi[28 * (size_t)i + 24] = i;
+    for (int k = 0; k < c->n_slots; k++) oi[28 * (size_t)si[k] + 23] = sm[k];
+    return RT_OK;
+}
+
+int rt_read_nodes48(rt_ctx* c, void* out) {
+    if (!c || !out) return RT_E_ARG;
+    if (!c->have_scene) return fail(c, RT_E_STATE, "no scene");
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = run_prep(c);
+    if (rc) return rc;
+    std::vector<float4> nb(2 * (size_t)c->n_visit);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (c->n_visit) HIPCK(c, hipMemcpy(nb.data(), c->nbox.p, nb.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    Std140Node* o = (Std140Node*)out;
+    for (int i = 0; i < c->n_nodes; i++) {
+        o[i] = c->h_nodes[i];
+        int v = c->node_first_visit[i];
+        if (v >= 0) {
+            o[i].aabbMin[0] = nb[2 * (size_t)v].x; o[i].aabbMin[1] = nb[2 * (size_t)v].y; o[i].aabbMin[2] = nb[2 * (size_t)v].z;
+            o[i].aabbMax[0] = nb[2 * (size_t)v + 1].x; o[i].aabbMax[1] = nb[2 * (size_t)v + 1].y; o[i].aabbMax[2] = nb[2 * (size_t)v + 1].z;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_set_camera(rt_ctx* c, const float vp[3], const float m[16], const float pos[3], float dof, float aa) {
+    if (!c || !vp || !m || !pos) return RT_E_ARG;
+    std::memcpy(c->cam.view_params, vp, 12);
+    std::memcpy(c->cam.l2w, m, 64);
+    std::memcpy(c->cam.cam_pos, pos, 12);
+    c->cam.dof = dof;
+    c->cam.aa = aa;
+    c->have_cam = true;
+    return RT_OK;
+}
+
+int rt_resize(rt_ctx* c, int w, int h) {
+    if (!c) return RT_E_ARG;
+    if (w <= 0 || h <= 0 || (int64_t)w * h > (1 << 28)) return fail(c, RT_E_ARG, "bad image size %dx%d", w, h);
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const bool own = (c->accum == c->accum_own.p);
+    HIPCK(c, c->accum_own.alloc((size_t)w * h * 3));
+    HIPCK(c, hipMemsetAsync(c->accum_own.p, 0, (size_t)w * h * 12, c->stream));
+    if (own || !c->accum) c->accum = c->accum_own.p;
+    c->cam.width = w;
+    c->cam.height = h;
+    c->n_accum = 0;
+    return RT_OK;
+}
+
+int rt_reset_accum(rt_ctx* c) {
+    if (!c) return RT_E_ARG;
+    if (!c->accum) return fail(c, RT_E_STATE, "no image size");
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, hipMemsetAsync(c->accum, 0, (size_t)c->cam.width * c->cam.height * 12, c->stream));
+    c->n_accum = 0;
+    return RT_OK;
+}
+
+int rt_bind_accum(rt_ctx* c, void* p) {
+    if (!c) return RT_E_ARG;
+    if (!p && !c->accum_own.p) return fail(c, RT_E_STATE, "no image size");
+    c->accum = p ? (float*)p : c->accum_own.p;
+    c->n_accum = 0;
+    return RT_OK;
+}
+
+int rt_set_accum_passes(rt_ctx* c, uint64_t n) {
+    if (!c) return RT_E_ARG;
+    c->n_accum = n;
+    c->sum_mode = true;
+    return RT_OK;
+}
+
+int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int rpp, int max_bounces, int flags) {
+    if (!c) return RT_E_ARG;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (rpp < 1 || max_bounces < 0 || stride < 1) return fail(c, RT_E_ARG, "bad sampling arguments");
+    if (flags != RT_ACCUM_MEAN && flags != RT_ACCUM_SUM) return fail(c, RT_E_ARG, "bad flags");
+    if (flags == RT_ACCUM_MEAN && stride != 1) return fail(c, RT_E_ARG, "running mean needs pass_stride 1");
+    HIPCK(c, hipSetDevice(c->device));
+    if ((rc = run_prep(c))) return rc;
+    RenderArgs a;
+    a.scene = scene_view(c);
+    a.cam = c->cam;
+    a.atmo = c->atmo;
+    a.accum = c->accum;
+    a.counters = c->counters.p;
+    a.pass_stride = stride;
+    a.rays_per_pixel = rpp;
+    a.max_bounces = max_bounces;
+    a.sum_mode = (flags == RT_ACCUM_SUM);
+    const dim3 grid((c->cam.width + 15) / 16, (c->cam.height + 15) / 16), block(RT_BLOCK);
+    // bound the length of one launch: at most ~2^27 camera samples per launch
+    const uint64_t per_pass = (uint64_t)c->cam.width * c->cam.height * (uint64_t)rpp;
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (1ull << 27) / std::max<uint64_t>(per_pass, 1));
+    hipEvent_t e0, e1;
+    HIPCK(c, hipEventCreate(&e0));
+    HIPCK(c, hipEventCreate(&e1));
+    HIPCK(c, hipEventRecord(e0, c->stream));
+    for (uint32_t done = 0; done < n_passes; done += chunk) {
+        a.first_pass = first + done * stride;
+        a.n_passes = std::min(chunk, n_passes - done);
+        if (c->stats_on) hipLaunchKernelGGL(k_render<true>, grid, block, 0, c->stream, a);
+        else hipLaunchKernelGGL(k_render<false>, grid, block, 0, c->stream, a);
+        c->st.launches++;
+    }
+    HIPCK(c, hipEventRecord(e1, c->stream));
+    c->pending_events.push_back({e0, e1});
+    HIPCK(c, hipGetLastError());
+    c->n_accum += n_passes;
+    c->sum_mode = (flags == RT_ACCUM_SUM);
+    c->st.samples += per_pass * n_passes;
+    return RT_OK;
+}
+
+int rt_first_hit(rt_ctx* c, uint32_t pass, int32_t* ids, float* ts) {
+    if (!c || !ids || !ts) return RT_E_ARG;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    HIPCK(c, hipSetDevice(c->device));
+    if ((rc = run_prep(c))) return rc;
+    const size_t n = (size_t)c->cam.width * c->cam.height;
+    DevBuf<int32_t> d_ids;
+    DevBuf<float> d_ts;
+    HIPCK(c, d_ids.alloc(n));
+    if (d_ts.alloc(n) != hipSuccess) { d_ids.release(); return fail(c, RT_E_DEVICE, "first_hit: out of device memory"); }
+    FirstHitArgs a;
+    a.scene = scene_view(c);
+    a.cam = c->cam;
+    a.atmo = c->atmo;
+    a.ids = d_ids.p;
+    a.ts = d_ts.p;
+    a.counters = c->counters.p;
+    a.pass = pass;
+    const dim3 grid((c->cam.width + 15) / 16, (c->cam.height + 15) / 16), block(RT_BLOCK);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, c->stream);
+    if (c->stats_on) hipLaunchKernelGGL(k_first_hit<true>, grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL(k_first_hit<false>, grid, block, 0, c->stream, a);
+    (void)hipEventRecord(e1, c->stream);
+    c->pending_events.push_back({e0, e1});
+    c->st.launches++;
+    c->st.samples += n;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(ids, d_ids.p, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ts, d_ts.p, n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    d_ids.release();
+    d_ts.release();
+    if (e != hipSuccess) return fail(c, RT_E_DEVICE, "first_hit: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_read_accum(rt_ctx* c, float* out, uint64_t* n_out) {
+    if (!c || !out) return RT_E_ARG;
+    if (!c->accum) return fail(c, RT_E_STATE, "no image size");
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, hipMemcpyAsync(out, c->accum, (size_t)c->cam.width * c->cam.height * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (n_out) *n_out = c->n_accum;
+    return RT_OK;
+}
+
+int rt_read_mean(rt_ctx* c, float* out) {
+    int rc = rt_read_accum(c, out, nullptr);
+    if (rc) return rc;
+    if (c->sum_mode && c->n_accum > 0) {
+        const float d = (float)c->n_accum;
+        const size_t n = (size_t)c->cam.width * c->cam.height * 3;
+        for (size_t i = 0; i < n; i++) out[i] = out[i] / d;
+    }
+    return RT_OK;
+}
+
+int rt_enable_stats(rt_ctx* c, int e) {
+    if (!c) return RT_E_ARG;
+    c->stats_on = e != 0;
+    return RT_OK;
+}
+
+int rt_reset_stats(rt_ctx* c) {
+    if (!c) return RT_E_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = resolve_events(c);
+    if (rc) return rc;
+    HIPCK(c, hipMemsetAsync(c->counters.p, 0, 32, c->stream));
+    c->st = rt_stats_t{};
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx* c, rt_stats_t* o) {
+    if (!c || !o) return RT_E_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = resolve_events(c);
+    if (rc) return rc;
+    unsigned long long h[4];
+    HIPCK(c, hipMemcpyAsync(h, c->counters.p, 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->st.rays = h[0]; c->st.box_tests = h[1]; c->st.tri_tests = h[2]; c->st.shaded_hits = h[3];
+    *o = c->st;
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx* c) {
+    if (!c) return RT_E_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+void* rt_stream(rt_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+}  // extern "C"

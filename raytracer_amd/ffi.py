@@ -1,0 +1,253 @@
+"""ctypes binding of include/rt_hip.h.
+
+``RtLib()`` loads ``raytracer_amd/librt_hip.so`` (the hand-written gfx950 kernels) and
+raises immediately if it is absent - there is NO CPU fallback in the product.  Tests may
+pass another path (the CPU oracle exports the same C-ABI) to drive both with one binding.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+HIP_LIB = Path(__file__).resolve().parent / "librt_hip.so"
+
+RT_ACCUM_MEAN = 0
+RT_ACCUM_SUM = 1
+
+
+class RtStats(C.Structure):
+    _fields_ = [
+        ("rays", C.c_uint64),
+        ("box_tests", C.c_uint64),
+        ("tri_tests", C.c_uint64),
+        ("shaded_hits", C.c_uint64),
+        ("samples", C.c_uint64),
+        ("kernel_ms", C.c_double),
+        ("launches", C.c_uint64),
+    ]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, where: str, text: str):
+        super().__init__(f"{where} failed with code {code}: {text}")
+        self.code = code
+
+
+_vp = C.c_void_p
+_SIGNATURES = {
+    "rt_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "rt_destroy": (C.c_int, [_vp]),
+    "rt_last_error": (C.c_char_p, [_vp]),
+    "rt_backend_name": (C.c_char_p, []),
+    "rt_set_scene": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "rt_set_materials": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "rt_update_mesh_transform": (C.c_int, [_vp, C.c_int, _vp]),
+    "rt_update_mesh_pose": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "rt_read_tris28": (C.c_int, [_vp, _vp]),
+    "rt_read_nodes48": (C.c_int, [_vp, _vp]),
+    "rt_set_camera": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float]),
+    "rt_resize": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "rt_reset_accum": (C.c_int, [_vp]),
+    "rt_bind_accum": (C.c_int, [_vp, _vp]),
+    "rt_render": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]),
+    "rt_first_hit": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
+    "rt_read_accum": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64)]),
+    "rt_read_mean": (C.c_int, [_vp, _vp]),
+    "rt_set_accum_passes": (C.c_int, [_vp, C.c_uint64]),
+    "rt_enable_stats": (C.c_int, [_vp, C.c_int]),
+    "rt_reset_stats": (C.c_int, [_vp]),
+    "rt_get_stats": (C.c_int, [_vp, C.POINTER(RtStats)]),
+    "rt_sync": (C.c_int, [_vp]),
+    "rt_stream": (_vp, [_vp]),
+}
+ABI_SYMBOLS = tuple(_SIGNATURES)
+
+
+def _ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _f32(a, shape=None) -> np.ndarray:
+    out = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and out.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {out.shape}")
+    return out
+
+
+class RtLib:
+    """A loaded C-ABI library."""
+
+    def __init__(self, path: str | Path | None = None):
+        path = Path(path) if path is not None else HIP_LIB
+        if not path.exists():
+            raise FileNotFoundError(
+                f"{path} is missing: the HIP extension must be built first "
+                f"(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+            )
+        self.path = path
+        self.dll = C.CDLL(str(path))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self.dll, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        self.backend = self.dll.rt_backend_name().decode()
+
+    def create(self, device: int = 0) -> "RtContext":
+        return RtContext(self, device)
+
+
+class RtContext:
+    """One rendering context (one GPU)."""
+
+    def __init__(self, lib: RtLib, device: int = 0):
+        self.lib = lib
+        self._h = _vp()
+        rc = lib.dll.rt_create(device, C.byref(self._h))
+        if rc != 0:
+            raise RtError(rc, "rt_create", "could not create context")
+        self.width = self.height = 0
+        self.n_tris = self.n_nodes = 0
+
+    # -- plumbing ----------------------------------------------------------------------
+    def _ck(self, rc: int, where: str) -> None:
+        if rc != 0:
+            raise RtError(rc, where, (self.lib.dll.rt_last_error(self._h) or b"").decode())
+
+    def close(self) -> None:
+        if self._h:
+            self.lib.dll.rt_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- scene ---------------------------------------------------------------------------
+    def set_scene(self, tris28, meshes128, nodes48, leaf_tri_ids, spheres96=None, atmosphere80=None) -> None:
+        tris = _f32(tris28).reshape(-1, 28)
+        meshes = np.ascontiguousarray(meshes128)
+        nodes = np.ascontiguousarray(nodes48)
+        ids = np.ascontiguousarray(leaf_tri_ids, dtype=np.int32)
+        sph = None if spheres96 is None or len(spheres96) == 0 else np.ascontiguousarray(spheres96)
+        atm = np.ascontiguousarray(atmosphere80)
+        assert meshes.dtype.itemsize == 128 and nodes.dtype.itemsize == 48 and atm.nbytes == 80
+        self._ck(
+            self.lib.dll.rt_set_scene(
+                self._h, _ptr(tris), tris.shape[0], _ptr(meshes), meshes.shape[0], _ptr(nodes), nodes.shape[0],
+                _ptr(ids), ids.shape[0], _ptr(sph), 0 if sph is None else sph.shape[0], _ptr(atm),
+            ),
+            "rt_set_scene",
+        )
+        self.n_tris, self.n_nodes = tris.shape[0], nodes.shape[0]
+
+    def set_materials(self, meshes128, atmosphere80=None) -> None:
+        meshes = np.ascontiguousarray(meshes128)
+        atm = None if atmosphere80 is None else np.ascontiguousarray(atmosphere80)
+        self._ck(self.lib.dll.rt_set_materials(self._h, _ptr(meshes), meshes.shape[0], _ptr(atm)), "rt_set_materials")
+
+    def update_mesh_transform(self, mesh: int, T44) -> None:
+        t = _f32(T44).reshape(16)
+        self._ck(self.lib.dll.rt_update_mesh_transform(self._h, mesh, _ptr(t)), "rt_update_mesh_transform")
+
+    def update_mesh_pose(self, mesh: int, pos, quat) -> None:
+        p, q = _f32(pos, (3,)), _f32(quat, (4,))
+        self._ck(self.lib.dll.rt_update_mesh_pose(self._h, mesh, _ptr(p), _ptr(q)), "rt_update_mesh_pose")
+
+    def read_tris28(self) -> np.ndarray:
+        out = np.empty((self.n_tris, 28), dtype=np.float32)
+        self._ck(self.lib.dll.rt_read_tris28(self._h, _ptr(out)), "rt_read_tris28")
+        return out
+
+    def read_nodes48(self, dtype) -> np.ndarray:
+        out = np.empty(self.n_nodes, dtype=dtype)
+        self._ck(self.lib.dll.rt_read_nodes48(self._h, _ptr(out)), "rt_read_nodes48")
+        return out
+
+    # -- camera / image ------------------------------------------------------------------------
+    def set_camera(self, view_params, local_to_world16, cam_pos, dof: float, aa: float) -> None:
+        vp, m, p = _f32(view_params, (3,)), _f32(local_to_world16).reshape(16), _f32(cam_pos, (3,))
+        self._ck(self.lib.dll.rt_set_camera(self._h, _ptr(vp), _ptr(m), _ptr(p), float(dof), float(aa)), "rt_set_camera")
+
+    def resize(self, width: int, height: int) -> None:
+        self._ck(self.lib.dll.rt_resize(self._h, width, height), "rt_resize")
+        self.width, self.height = width, height
+
+    def reset_accum(self) -> None:
+        self._ck(self.lib.dll.rt_reset_accum(self._h), "rt_reset_accum")
+
+    def bind_accum(self, ptr: int | None) -> None:
+        self._ck(self.lib.dll.rt_bind_accum(self._h, _vp(ptr) if ptr else None), "rt_bind_accum")
+
+    def set_accum_passes(self, n: int) -> None:
+        self._ck(self.lib.dll.rt_set_accum_passes(self._h, n), "rt_set_accum_passes")
+
+    # -- work ------------------------------------------------------------------------------------
+    def render(self, first_pass: int, n_passes: int, pass_stride: int = 1, rays_per_pixel: int = 1,
+               max_bounces: int = 1, flags: int = RT_ACCUM_MEAN) -> None:
+        self._ck(
+            self.lib.dll.rt_render(self._h, first_pass, n_passes, pass_stride, rays_per_pixel, max_bounces, flags),
+            "rt_render",
+        )
+
+    def first_hit(self, pass_index: int = 1) -> tuple[np.ndarray, np.ndarray]:
+        ids = np.empty((self.height, self.width), dtype=np.int32)
+        ts = np.empty((self.height, self.width), dtype=np.float32)
+        self._ck(self.lib.dll.rt_first_hit(self._h, pass_index, _ptr(ids), _ptr(ts)), "rt_first_hit")
+        return ids, ts
+
+    def read_accum(self) -> tuple[np.ndarray, int]:
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        n = C.c_uint64(0)
+        self._ck(self.lib.dll.rt_read_accum(self._h, _ptr(out), C.byref(n)), "rt_read_accum")
+        return out, int(n.value)
+
+    def read_mean(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        self._ck(self.lib.dll.rt_read_mean(self._h, _ptr(out)), "rt_read_mean")
+        return out
+
+    # -- counters ------------------------------------------------------------------------------------
+    def enable_stats(self, on: bool = True) -> None:
+        self._ck(self.lib.dll.rt_enable_stats(self._h, int(on)), "rt_enable_stats")
+
+    def reset_stats(self) -> None:
+        self._ck(self.lib.dll.rt_reset_stats(self._h), "rt_reset_stats")
+
+    def stats(self) -> dict:
+        s = RtStats()
+        self._ck(self.lib.dll.rt_get_stats(self._h, C.byref(s)), "rt_get_stats")
+        return s.as_dict()
+
+    def sync(self) -> None:
+        self._ck(self.lib.dll.rt_sync(self._h), "rt_sync")
+
+    def stream(self) -> int:
+        return int(self.lib.dll.rt_stream(self._h) or 0)
+
+    # -- convenience: a whole Scene object ----------------------------------------------------------
+    def load_scene(self, scene, rest_pose: bool = True) -> None:
+        """Upload a ``scripts.classes.Scene``: rest-pose geometry + per-mesh poses applied on
+        the device (rest_pose=True), or host-posed geometry as the reference uploads it."""
+        from .scripts import functions as F
+
+        if not rest_pose:
+            F.pose_dirty_meshes_on_host(scene)
+        b = F.export_scene_buffers(scene, rest_pose=rest_pose)
+        self.set_scene(b["tris28"], b["meshes128"], b["nodes48"], b["leaf_tri_ids"], b["spheres96"], b["atmosphere80"])
+        if rest_pose:
+            for mesh in scene.meshes:
+                self.update_mesh_pose(mesh.id, mesh.csys.pos, mesh.csys.quat)
+                mesh.unflag_for_mesh_update()
+
+    def load_camera(self, cam) -> None:
+        from .scripts import functions as F
+
+        u = F.camera_uniforms(cam)
+        self.set_camera(u["view_params"], u["local_to_world16"], u["cam_pos"], u["dof"], u["aa"])

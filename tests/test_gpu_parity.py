@@ -1,0 +1,92 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+
+Bar (BASELINE.json north_star): primary-ray first-hit triangle ids bit-exact; accumulated
+radiance within 1e-3 relative at matched seeds.  Because both sides implement the same
+float32 arithmetic contract the tests below demand MORE: bit-identical ids,
+distances and radiance, with zero pixels excluded.
+"""
+import numpy as np
+import pytest
+
+from conftest import build_suzanne, make_ctx
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(oracle_lib, hip_lib, w, h, frame=0):
+    sc = build_suzanne(frame)
+    o = make_ctx(oracle_lib, sc, w, h)
+    sc2 = build_suzanne(frame)
+    g = make_ctx(hip_lib, sc2, w, h)
+    return o, g
+
+
+def test_backend_is_hip(hip_lib):
+    assert hip_lib.backend == "hip"
+
+
+def test_pose_and_refit_bit_exact(oracle_lib, hip_lib):
+    from raytracer_amd.scripts.scenes.chunker import NODE_DTYPE
+
+    o, g = _pair(oracle_lib, hip_lib, 64, 36)
+    to, tg = o.read_tris28(), g.read_tris28()
+    assert np.array_equal(to.view(np.uint32), tg.view(np.uint32))
+    no, ng = o.read_nodes48(NODE_DTYPE), g.read_nodes48(NODE_DTYPE)
+    assert no.tobytes() == ng.tobytes()
+
+
+@pytest.mark.parametrize("size", [(64, 36), (320, 180), (333, 187)])
+def test_first_hit_bit_exact(oracle_lib, hip_lib, size):
+    o, g = _pair(oracle_lib, hip_lib, *size)
+    for p in (1, 7):
+        io, to = o.first_hit(p)
+        ig, tg = g.first_hit(p)
+        assert np.array_equal(io, ig), f"{(io != ig).sum()} first-hit ids differ"
+        assert np.array_equal(to.view(np.uint32), tg.view(np.uint32))
+    assert (io >= 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("bounces,rpp,passes", [(0, 1, 1), (2, 1, 1), (4, 1, 6), (8, 2, 3)])
+def test_radiance_bit_exact_running_mean(oracle_lib, hip_lib, bounces, rpp, passes):
+    o, g = _pair(oracle_lib, hip_lib, 160, 90)
+    o.render(1, passes, 1, rpp, bounces, 0)
+    g.render(1, passes, 1, rpp, bounces, 0)
+    a, b = o.read_mean(), g.read_mean()
+    assert np.isfinite(a).all()
+    if bounces >= 2:
+        assert a.max() > 0          # the light is only seen indirectly from this camera
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).any(axis=2).sum()} pixels differ"
+
+
+def test_radiance_sum_mode_strided(oracle_lib, hip_lib):
+    o, g = _pair(oracle_lib, hip_lib, 96, 54)
+    o.render(2, 3, 4, 1, 4, 1)
+    g.render(2, 3, 4, 1, 4, 1)
+    (a, na), (b, nb) = o.read_accum(), g.read_accum()
+    assert na == nb == 3
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(o.read_mean(), g.read_mean())
+
+
+def test_counters_match_oracle(oracle_lib, hip_lib):
+    o, g = _pair(oracle_lib, hip_lib, 96, 54)
+    g.enable_stats(True)
+    o.reset_stats(); g.reset_stats()
+    o.render(1, 2, 1, 1, 4, 0)
+    g.render(1, 2, 1, 1, 4, 0)
+    so, sg = o.stats(), g.stats()
+    assert so["rays"] == sg["rays"] and so["shaded_hits"] == sg["shaded_hits"]
+    # the product walks the same boxes/triangles minus redundant leaf re-tests
+    assert sg["tri_tests"] == so["tri_tests"]
+    assert 0 < sg["box_tests"] <= so["box_tests"]
+    assert sg["kernel_ms"] > 0
+
+
+def test_animated_frame_parity(oracle_lib, hip_lib):
+    o, g = _pair(oracle_lib, hip_lib, 128, 72, frame=100)
+    io, _ = o.first_hit(1)
+    ig, _ = g.first_hit(1)
+    assert np.array_equal(io, ig)
+    o.render(1, 2, 1, 1, 4, 0)
+    g.render(1, 2, 1, 1, 4, 0)
+    assert np.array_equal(o.read_mean().view(np.uint32), g.read_mean().view(np.uint32))
