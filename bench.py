@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py - Mrays/s of the rendering hot path on BASELINE.json configs[1]:
+Suzanne room, 1920x1080, 64 spp as 64 passes x 1 ray/pixel, 4 bounces, one MI355X.
+
+A "step" = one full render of that frame (64 passes looped in one k_render launch, scene and
+accumulator resident in HBM).  ray = one closest-hit query (calculateRayCollision,
+shaders/raytracer.fs.glsl:518-641 of the reference), counted exactly in-kernel by a
+separate counting launch of the same deterministic work.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling - every rank renders
+64 passes of the same frame with its own pass indices (rank r takes 1+r, 1+r+N, ...), i.e.
+64*N spp in total, into a SUM accumulator; one RCCL all-reduce per step combines them
+(the exchange step the path really has).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WIDTH, HEIGHT, PASSES, RPP, BOUNCES = 1920, 1080, 64, 1, 4
+# algorithmic work per unit (DESIGN.md "roofline accounting")
+FLOP_BOX, FLOP_TRI, FLOP_HIT = 27, 47, 160
+BYTE_BOX, BYTE_TRI, BYTE_HIT = 32, 36, 48
+PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak (= dense f32 MFMA peak), MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-passes", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd import ffi
+    from raytracer_amd.scripts.scenes import final_scene_numba as S
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---- scene + context (inputs resident in HBM before the timed region) ----
+    scene = S.build()
+    scene.animate_frame(0)
+    lib = ffi.RtLib()                      # hand-written HIP kernels; raises if missing
+    ctx = lib.create(local_rank)
+    ctx.load_scene(scene)
+    ctx.load_camera(scene.cam)
+    ctx.resize(WIDTH, HEIGHT)
+    accum = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)     # kernels, events and the all-reduce share one stream
+    ctx.bind_accum(accum.data_ptr())
+
+    sum_mode = world > 1
+    first_pass, stride = (1 + rank, world) if sum_mode else (1, 1)
+
+    def step():
+        ctx.reset_accum()
+        ctx.render(first_pass, PASSES, stride, RPP, BOUNCES, ffi.RT_ACCUM_SUM if sum_mode else ffi.RT_ACCUM_MEAN)
+        if sum_mode:
+            dist.all_reduce(accum)         # RCCL over xGMI; same stream as the render
+            ctx.set_accum_passes(PASSES * world)
+
+    # ---- counting launch: exact rays / box tests / triangle tests / hits of one step ----
+    ctx.enable_stats(True)
+    ctx.reset_stats()
+    step()
+    torch.cuda.synchronize(dev)
+    counts = ctx.stats()
+    ctx.enable_stats(False)
+    cvec = torch.tensor([counts["rays"], counts["box_tests"], counts["tri_tests"], counts["shaded_hits"]],
+                        dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(cvec)
+    rays_step, box_step, tri_step, hit_step = (float(x) for x in cvec.tolist())
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    ctx.reset_stats()
+
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # ---- dominant kernel: average launch duration by HIP events on the launch stream ----
+    st = ctx.stats()
+    launches = max(int(st["launches"]), 1)
+    kern_ms = st["kernel_ms"] / launches
+    # per-launch algorithmic work of THIS rank (rank 0 reports its own kernel)
+    flop_launch = (FLOP_BOX * counts["box_tests"] + FLOP_TRI * counts["tri_tests"] + FLOP_HIT * counts["shaded_hits"])
+    byte_launch = (BYTE_BOX * counts["box_tests"] + BYTE_TRI * counts["tri_tests"] + BYTE_HIT * counts["shaded_hits"]
+                   + 24 * WIDTH * HEIGHT)   # accumulator read + write once per launch
+    flop_launch /= max(1, launches // max(args.steps, 1))
+    byte_launch /= max(1, launches // max(args.steps, 1))
+    achieved_tflops = flop_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    achieved_gbs = byte_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+
+    traffic = None
+    pmc = ROOT / "profiles" / "pmc_latest.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    value = rays_step * args.steps / dt / 1e6
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_passes)
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/sec, Suzanne 1080p (rays = closest-hit queries, counted in-kernel)",
+            "value": round(value, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic: Suzanne room from the reference's OBJ assets, camera = keyframe 0, RNG seeds = pass 1..64",
+            "config": {
+                "workload": f"configs[1]: Suzanne {WIDTH}x{HEIGHT}, {PASSES} spp ({PASSES} passes x {RPP} ray/px), "
+                            f"{BOUNCES} bounces, per GPU",
+                "parallelism": "1 GPU, running mean" if world == 1 else
+                               f"spp-sharded x{world} (pass stride {world}) + RCCL all-reduce of the {WIDTH*HEIGHT*12/1e6:.1f} MB sum",
+                "rays_per_step": int(rays_step),
+                "box_tests_per_ray": round(box_step / rays_step, 2),
+                "tri_tests_per_ray": round(tri_step / rays_step, 2),
+                "hits_per_ray": round(hit_step / rays_step, 3),
+            },
+            "roofline": {
+                "bound": "valu",
+                "kernel": "k_render<false>",
+                "achieved": round(achieved_tflops, 3),
+                "peak": PEAK_FP32_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved_tflops / PEAK_FP32_TFLOPS, 4),
+                "traffic": traffic,
+                "avg_launch_ms": round(kern_ms, 3),
+                "hbm": {"achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(achieved_gbs / PEAK_HBM_GBS, 4),
+                        "note": "algorithmic bytes as if every node/triangle fetch went to HBM"},
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(passes: int) -> dict:
+    """The CPU oracle (a port: the reference has no CPU renderer) on a bounded sample of the
+    same workload: same scene/camera/seeds, the first `passes` of the 64 passes."""
+    from raytracer_amd import ffi
+    from raytracer_amd.scripts.scenes import final_scene_numba as S
+
+    lib = ffi.RtLib(ROOT / "oracle" / "librt_oracle.so")
+    lib.dll.rto_set_threads.restype = int
+    threads = int(lib.dll.rto_set_threads(int(os.environ.get("OMP_NUM_THREADS", "0") or 0)))
+    scene = S.build()
+    scene.animate_frame(0)
+    ctx = lib.create(0)
+    ctx.load_scene(scene)
+    ctx.load_camera(scene.cam)
+    ctx.resize(WIDTH, HEIGHT)
+    ctx.reset_stats()
+    t0 = time.perf_counter()
+    ctx.render(1, passes, 1, RPP, BOUNCES, ffi.RT_ACCUM_MEAN)
+    dt = time.perf_counter() - t0
+    rays = ctx.stats()["rays"]
+    ctx.close()
+    return {
+        "value": round(rays / dt / 1e6, 3),
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"oracle/rt_oracle.c (OpenMP), same scene/camera/seeds, {WIDTH}x{HEIGHT}, passes 1..{passes} of {PASSES}, "
+                  f"{BOUNCES} bounces: {rays} rays in {dt:.2f} s",
+    }
+
+
+if __name__ == "__main__":
+    main()

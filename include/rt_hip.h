@@ -136,6 +136,10 @@ int rt_enable_stats(rt_ctx* ctx, int enable);
 int rt_reset_stats(rt_ctx* ctx);
 int rt_get_stats(rt_ctx* ctx, rt_stats_t* out);
 
+/* launch on a caller-provided hipStream_t (e.g. torch's current stream, so that a
+ * torch.distributed all-reduce of the bound accumulator is ordered after the render
+ * without a host sync); NULL returns to the context's own stream.  Oracle: no-op. */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 /* block until all work of the context is done (hipStreamSynchronize) */
 int rt_sync(rt_ctx* ctx);
 /* the hipStream_t the context launches on, as an opaque pointer (for event timing) */

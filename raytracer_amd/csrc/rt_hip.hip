@@ -275,7 +275,8 @@ struct DevBuf {
 
 struct rt_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // stream in use
+    hipStream_t own_stream = nullptr;   // created by rt_create
     char err[512] = {0};
     // scene (device)
     DevBuf<float4> rest, geo, nrm, nodes, roots, nbox;
@@ -425,9 +426,10 @@ int rt_create(int device, rt_ctx** out) {
     rt_ctx* c = new (std::nothrow) rt_ctx();
     if (!c) return RT_E_NOMEM;
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
+    c->stream = c->own_stream;
     if (c->counters.alloc(4) != hipSuccess || hipMemsetAsync(c->counters.p, 0, 32, c->stream) != hipSuccess) {
-        (void)hipStreamDestroy(c->stream);
+        (void)hipStreamDestroy(c->own_stream);
         delete c;
         return RT_E_DEVICE;
     }
@@ -451,7 +453,7 @@ int rt_destroy(rt_ctx* c) {
     free_scene(c);
     c->accum_own.release();
     c->counters.release();
-    (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RT_OK;
 }
@@ -874,5 +876,15 @@ int rt_sync(rt_ctx* c) {
 }
 
 void* rt_stream(rt_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int rt_set_stream(rt_ctx* c, void* s) {
+    if (!c) return RT_E_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = resolve_events(c);          // events belong to the old stream
+    if (rc) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return RT_OK;
+}
 
 }  // extern "C"

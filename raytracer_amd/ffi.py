@@ -63,6 +63,7 @@ _SIGNATURES = {
     "rt_reset_stats": (C.c_int, [_vp]),
     "rt_get_stats": (C.c_int, [_vp, C.POINTER(RtStats)]),
     "rt_sync": (C.c_int, [_vp]),
+    "rt_set_stream": (C.c_int, [_vp, _vp]),
     "rt_stream": (_vp, [_vp]),
 }
 ABI_SYMBOLS = tuple(_SIGNATURES)
@@ -227,6 +228,9 @@ class RtContext:
 
     def sync(self) -> None:
         self._ck(self.lib.dll.rt_sync(self._h), "rt_sync")
+
+    def set_stream(self, hip_stream: int | None) -> None:
+        self._ck(self.lib.dll.rt_set_stream(self._h, _vp(hip_stream) if hip_stream else None), "rt_set_stream")
 
     def stream(self) -> int:
         return int(self.lib.dll.rt_stream(self._h) or 0)
