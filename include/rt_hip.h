@@ -131,6 +131,14 @@ int rt_read_mean(rt_ctx* ctx, float* out_whc);
 /* tell the context how many passes an externally combined (all-reduced) SUM now holds */
 int rt_set_accum_passes(rt_ctx* ctx, uint64_t n_passes);
 
+/* Traversal mode.  0 (default) = STRICT: every box the reference would open is opened, so
+ * results equal the oracle bit-for-bit.  1 = CULL: boxes wholly behind the ray origin or
+ * wholly beyond the current closest hit (with a 2^-10 relative+absolute safety band) are
+ * skipped; differs from STRICT only for rays whose triangle distance is off by more than
+ * that band (grazing incidence, DESIGN.md "culling").  No reference counterpart (the
+ * reference never culls, raytracer.fs.glsl:558-632). */
+int rt_set_cull(rt_ctx* ctx, int enable);
+
 /* counters: enable => launches use the counting kernel variant (slower; not for timing) */
 int rt_enable_stats(rt_ctx* ctx, int enable);
 int rt_reset_stats(rt_ctx* ctx);

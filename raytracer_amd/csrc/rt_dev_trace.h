@@ -1,4 +1,4 @@
-// rt_dev_trace.h - device data layout, closest-hit query and the bounce loop (gfx950).
+// rt_dev_trace.h - device data layout and the wave-scheduled path tracer (gfx950).
 //
 // Restates, for one ray per lane of a 64-wide wavefront:
 //   boundingBoxIntersect   shaders/raytracer.fs.glsl:421-453
@@ -8,6 +8,7 @@
 //   raySphere              :251-276
 //   calculateRayCollision  :518-641
 //   traceRay               :691-915
+//   main()                 :928-1044
 //
 // Data layout in HBM (built by rt_set_scene, refreshed by the prep kernels):
 //   tri_geo  4 x float4 per triangle SLOT (64 B, one half cache line):
@@ -15,20 +16,35 @@
 //            slots are in traversal order of the reference (mesh ascending, depth-first,
 //            second child first, leaf order), so (a) every leaf and every subtree is one
 //            contiguous range, (b) the slot index is the rank that decides ties exactly as
-//            the reference's "first found wins" (strict <, :625).  rem = triangles left in
-//            the leaf after this one, so a leaf is walked with no separate count fetch.
-//   tri_nrm  3 x float4 per slot (corner normals), touched only for the winning triangle.
+//            the reference's "first found wins" (strict <, :625) whatever order the kernel
+//            visits nodes in.  rem = triangles left in the leaf after this one.
+//   tri_nrm  3 x float4 per slot (corner normals; .w of the first = mesh index).
 //   nodes    4 x float4 per INTERIOR node: both children's boxes and references
 //              {lo1.xyz, bits(ref1)} {hi1.xyz, bits(ref2)} {lo2.xyz, 0} {hi2.xyz, 0}
 //            ref >= 0: interior record index; ref < 0 and != RT_NONE: leaf, first slot = ~ref.
 //   roots    2 x float4 per mesh: {lo.xyz, bits(ref)} {hi.xyz, 0} of the mesh's root node.
 //   mats     the 80-byte std140 Material of every mesh, as uploaded.
+//
+// Execution model: every lane owns one pixel and runs a small state machine.  In the
+// traversal phase the wave votes (ballot + popcount) between "one interior node" and "one
+// triangle" and executes the block more lanes are waiting for; when fewer than
+// `refill_below` lanes are still traversing, the waiting lanes shade their hits and start
+// their next ray (next bounce, next sample or next pass) in one path block.  A block thus
+// runs with a well-filled EXEC mask instead of the 20 % lane utilisation a nested per-lane
+// loop nest measures here (profiles/pmc_r1a).  The order of operations seen by any one lane is
+// unchanged, so results do not depend on the votes.
 #pragma once
 #include "rt_dev_math.h"
 
 #define RT_NONE ((int)0x80000000)
 #define RT_BLOCK 256
-#define RT_STACK 32
+#define RT_MISS_RANK 0x7fffffff
+#define RT_SPHERE_RANK (-(1 << 30))
+
+// conservative culling band (CULL builds only): a box is skipped when it lies wholly behind
+// the origin by more than RT_CULL_ABS, or wholly beyond best_t*(1+RT_CULL_REL)+RT_CULL_ABS.
+#define RT_CULL_ABS 0x1p-10f
+#define RT_CULL_REL 0x1p-10f
 
 struct MatDev {          // std140 Material, 80 bytes (raytracer.fs.glsl:53-68)
     float color[4];
@@ -51,6 +67,7 @@ struct DevScene {
     const SphereDev* spheres;
     int n_meshes;
     int n_spheres;
+    int stack_depth;      // stack entries a lane can need (max tree depth + 1)
 };
 
 struct DevCamera {
@@ -63,152 +80,31 @@ struct DevCamera {
 
 struct Counters { unsigned long long rays, box, tri, hits; };
 
-#define RT_SPHERE_RANK (-(1 << 30))
-
-struct Hit {
-    float t;    // 1e20 = miss
-    int rank;   // slot index of the triangle; RT_SPHERE_RANK + i for sphere i; INT_MAX = miss
-};
-
-// the reference's slab test, comparison for comparison (NaN compares false, no t >= 0 test)
-__device__ __forceinline__ bool box_hit(v3 o, v3 inv, float4 lo, float4 hi) {
+// The reference's slab test, comparison for comparison (NaN compares false, no t >= 0 test).
+// On a hit, [tmin, tmax] is the entry/exit interval the reference ends up with.
+__device__ __forceinline__ bool box_test(v3 o, v3 inv, float4 lo, float4 hi, float& tmin_out, float& tmax_out) {
     float tmin = (lo.x - o.x) * inv.x, tmax = (hi.x - o.x) * inv.x, t;
     if (tmin > tmax) { t = tmin; tmin = tmax; tmax = t; }
     float tymin = (lo.y - o.y) * inv.y, tymax = (hi.y - o.y) * inv.y;
     if (tymin > tymax) { t = tymin; tymin = tymax; tymax = t; }
-    if ((tmin > tymax) || (tymin > tmax)) return false;
+    bool hit = !((tmin > tymax) || (tymin > tmax));
     if (tymin > tmin) tmin = tymin;
     if (tymax < tmax) tmax = tymax;
     float tzmin = (lo.z - o.z) * inv.z, tzmax = (hi.z - o.z) * inv.z;
     if (tzmin > tzmax) { t = tzmin; tzmin = tzmax; tzmax = t; }
-    if ((tmin > tzmax) || (tzmin > tmax)) return false;
-    return true;
+    hit = hit && !((tmin > tzmax) || (tzmin > tmax));
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    tmin_out = tmin;
+    tmax_out = tmax;
+    return hit;
 }
 
-// Closest hit over spheres and all mesh BVHs.  prev_id = triId of the triangle the ray
-// left (-1 none), prev_mesh / in_solid as in Ray.prevHit / Ray.inSolid.
-template <bool STATS>
-__device__ __forceinline__ Hit closest_hit(const DevScene& S, v3 o, v3 d, int prev_id, int prev_mesh, bool in_solid,
-                                           int* stack /* LDS, this lane's column, stride RT_BLOCK */, Counters& cnt) {
-    Hit best;
-    best.t = 1e20f;
-    best.rank = 0x7fffffff;
-    if (STATS) cnt.rays++;
-    const v3 inv = V3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-
-    for (int i = 0; i < S.n_spheres; i++) {                     // :525-541
-        const SphereDev& sp = S.spheres[i];
-        v3 c = V3(sp.position[0], sp.position[1], sp.position[2]);
-        v3 oo = o - c;
-        float a = dot3(d, d);
-        float b = 2.0f * dot3(oo, d);
-        float cc = dot3(oo, oo) - sp.radius * sp.radius;
-        float disc = b * b - (4.0f * a) * cc;
-        if (disc >= 0.0f) {
-            float dst = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
-            if (dst >= 0.0f && !(dst < 1e-6f) && dst < best.t) { best.t = dst; best.rank = RT_SPHERE_RANK + i; }
-        }
-    }
-
-    int sp = 0;          // stack entries of this lane
-    int j = 0;           // next mesh whose root has not been started
-    int cur = RT_NONE;   // reference (interior >= 0 / leaf < 0) being visited
-    bool hb = false;     // hitBehind for the mesh being walked
-    // Stack entries carry no mesh tag: a mesh's subtree is finished (stack empty) before
-    // the next root is started, so hb always belongs to `cur`.
-    while (true) {
-        if (cur == RT_NONE) {
-            if (sp > 0) {
-                cur = stack[(--sp) * RT_BLOCK];
-            } else {
-                if (j >= S.n_meshes) break;
-                float4 r0 = S.roots[2 * j], r1 = S.roots[2 * j + 1];
-                int ref = __float_as_int(r0.w);
-                // hitBehind for triangles of mesh j (:605-615; in a solid: same mesh only [9.6])
-                hb = in_solid ? (prev_mesh == j) : (S.mats[j].transparentFromBehind == 0);
-                if (ref < 0 && ref != RT_NONE) {                  // root is a leaf: the reference tests its own box (:586)
-                    if (STATS) cnt.box++;
-                    if (!box_hit(o, inv, r0, r1)) ref = RT_NONE;
-                }
-                cur = ref;
-                j++;
-                continue;
-            }
-        }
-        if (cur >= 0) {                                          // interior: test both children (:562-584)
-            const float4* n = S.nodes + 4 * (size_t)cur;
-            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-            int ref1 = __float_as_int(n0.w), ref2 = __float_as_int(n1.w);
-            bool h1 = false, h2 = false;
-            if (ref1 != RT_NONE) { if (STATS) cnt.box++; h1 = box_hit(o, inv, n0, n1); }
-            if (ref2 != RT_NONE) { if (STATS) cnt.box++; h2 = box_hit(o, inv, n2, n3); }
-            if (h1 && h2) { stack[(sp++) * RT_BLOCK] = ref1; cur = ref2; }
-            else if (h2) cur = ref2;
-            else if (h1) cur = ref1;
-            else cur = RT_NONE;
-            continue;
-        }
-        // leaf: walk its slots (:593-630)
-        int k = ~cur;
-        int rem;
-        do {
-            const float4* g = S.tri_geo + 4 * (size_t)k;
-            float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-            rem = __float_as_int(g3.y);
-            if (__float_as_int(g3.z) != prev_id) {
-                if (STATS) cnt.tri++;
-                v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
-                v3 N = V3(g0.w, g1.w, g2.w);
-                float nd = dot3(N, d);
-                bool ok = !(__builtin_fabsf(nd) < 1e-6f) && !(nd > 0.0f && !hb);
-                float t = -(dot3(N, o) + g3.x) / nd;
-                ok = ok && !(t < 0.0f) && !(t < 1e-6f);
-                // closer than (or tied with a later-ranked) current best; NaN t never wins
-                ok = ok && (t < best.t || (t == best.t && k < best.rank));
-                if (ok) {
-                    v3 P = madd3(o, t, d);
-                    v3 c0 = cross3(B - A, P - A);
-                    if (!(dot3(N, c0) < 0.0f)) {
-                        v3 c1 = cross3(C - B, P - B);
-                        if (!(dot3(N, c1) < 0.0f)) {
-                            v3 c2 = cross3(A - C, P - C);
-                            if (!(dot3(N, c2) < 0.0f)) { best.t = t; best.rank = k; }
-                        }
-                    }
-                }
-            }
-            k++;
-        } while (rem > 0);
-        cur = RT_NONE;
-    }
-    return best;
-}
-
-struct PathState {
-    v3 origin, dir;
-    int prev_id, prev_mesh;      // Ray.prevHit.facetId / meshIndex
-    float prev_color[4];         // Ray.prevHit.material.color
-    float prev_transmission;     // Ray.prevHit.material.transmission
-    float ior;
-    bool in_solid;
-};
-
-// camera sample (raytracer.fs.glsl:972-987); four draws: DoF x,y then AA x,y
-__device__ __forceinline__ void new_sample_ray(const DevCamera& cam, const MatDev& atmo, v3 view_point, uint32_t& rng, PathState& r) {
-    float r1 = random_value(rng), r2 = random_value(rng), r3 = random_value(rng), r4 = random_value(rng);
-    float nearp = cam.view_params[2];
-    v3 dofo = V3(((r1 * 2.0f - 1.0f) * cam.dof) * nearp, ((r2 * 2.0f - 1.0f) * cam.dof) * nearp,
-                 ((0.0f * 2.0f - 1.0f) * cam.dof) * nearp);
-    v3 aao = V3((r3 * 2.0f - 1.0f) * cam.aa, (r4 * 2.0f - 1.0f) * cam.aa, (0.0f * 2.0f - 1.0f) * cam.aa);
-    r.dir = normalize3((view_point + dofo) + aao);
-    r.origin = V3(cam.cam_pos[0], cam.cam_pos[1], cam.cam_pos[2]) - dofo;
-    r.prev_id = -1;
-    r.prev_mesh = -1;
-    r.prev_color[0] = atmo.color[0]; r.prev_color[1] = atmo.color[1];
-    r.prev_color[2] = atmo.color[2]; r.prev_color[3] = atmo.color[3];
-    r.prev_transmission = atmo.transmission;
-    r.ior = atmo.ior;
-    r.in_solid = false;
+// true when the culling band allows skipping a box with interval [tmin,tmax]; NaN never culls
+template <bool CULL>
+__device__ __forceinline__ bool culled(float tmin, float tmax, float best_t) {
+    if (!CULL) return false;
+    return (tmax < -RT_CULL_ABS) || (tmin > fma_(best_t, RT_CULL_REL, best_t) + RT_CULL_ABS);
 }
 
 // fragPosition -> world-space view point (raytracer.fs.glsl:961-962, raytracer.vs.glsl:6-9)
@@ -227,105 +123,377 @@ __device__ __forceinline__ v3 view_point_of(const DevCamera& cam, int px, int py
     return V3(r[0], r[1], r[2]);
 }
 
-// One camera sample: the bounce loop of traceRay.  Returns incoming light.
-template <bool STATS>
-__device__ __forceinline__ v3 trace_path(const DevScene& S, const MatDev& atmo, PathState& ray, uint32_t& rng,
-                                         int max_bounces, int* stack, Counters& cnt) {
-    v3 incoming = V3(0.0f, 0.0f, 0.0f), color = V3(1.0f, 1.0f, 1.0f);
-    for (int i = 0; i <= max_bounces; i++) {
-        Hit h = closest_hit<STATS>(S, ray.origin, ray.dir, ray.prev_id, ray.prev_mesh, ray.in_solid, stack, cnt);
-        if (h.rank == 0x7fffffff) break;                          // miss: environment light is vec3(0) (:279-282)
-        if (STATS) cnt.hits++;
-        // ---- rebuild the HitInfo of the winner -------------------------------------------------
-        v3 hit_point = madd3(ray.origin, h.t, ray.dir);
-        v3 normal;
-        bool backside = false;
-        int hit_id = -1, hit_mesh = -1;
-        const MatDev* m;
-        if (h.rank < 0) {                                         // sphere
-            const SphereDev& sp = S.spheres[h.rank - RT_SPHERE_RANK];
-            normal = normalize3(hit_point - V3(sp.position[0], sp.position[1], sp.position[2]));
-            m = &sp.material;
-        } else {
-            const float4* g = S.tri_geo + 4 * (size_t)h.rank;
-            float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-            v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z), N = V3(g0.w, g1.w, g2.w);
-            backside = dot3(N, ray.dir) > 0.0f;
-            float area = length3(N) / 2.0f;
-            float w = length3(cross3(B - A, hit_point - A)) / 2.0f / area;
-            float u = length3(cross3(C - B, hit_point - B)) / 2.0f / area;
-            float v = 1.0f - u - w;
-            const float4* nn = S.tri_nrm + 3 * (size_t)h.rank;
-            float4 na = nn[0], nb = nn[1], nc = nn[2];
-            normal = V3(na.x * u + nb.x * v + nc.x * w, na.y * u + nb.y * v + nc.y * w, na.z * u + nb.z * v + nc.z * w);
-            hit_id = __float_as_int(g3.z);
-            hit_mesh = __float_as_int(na.w);
-            m = &S.mats[hit_mesh];
-        }
-        // ---- material response (:720-898) -------------------------------------------------------
-        float alpha = m->color[3];
-        if (alpha < 0.99999f) {
-            if (random_value(rng) > alpha) {                      // pass straight through
-                if (i == max_bounces) break;
-                ray.origin = hit_point;
-                ray.prev_id = hit_id; ray.prev_mesh = hit_mesh;
-                ray.prev_color[0] = m->color[0]; ray.prev_color[1] = m->color[1];
-                ray.prev_color[2] = m->color[2]; ray.prev_color[3] = alpha;
-                ray.prev_transmission = m->transmission;
-                continue;
-            }
-        }
-        float es = m->emissionStrength;
-        incoming = incoming + V3(m->emissionColor[0] * es, m->emissionColor[1] * es, m->emissionColor[2] * es) * color;
+enum { M_NODE = 0, M_TRI = 1, M_PATH = 2, M_DONE = 3 };
 
-        float nf = backside ? -1.0f : 1.0f;
-        v3 nrm = normal * nf;
-        float n2 = (ray.in_solid && backside) ? atmo.ior : m->ior;
-        float n1 = ray.ior;
-        v3 diffuse = normalize3((-nrm) + random_direction(rng));
-        float costheta = clampf(dot3(normalize3(nrm), normalize3(-ray.dir)), -1.0f, 1.0f);
-        float r0 = (n1 - n2) / (n1 + n2);
-        r0 = r0 * r0;
-        float om = 1.0f - costheta;
-        float om5 = ((om * om) * (om * om)) * om;
-        float schlick = r0 + (1.0f - r0) * om5;
+struct TraceArgs {
+    DevScene scene;
+    DevCamera cam;
+    MatDev atmo;
+    float* accum;                 // W*H*3 (render)
+    int32_t* ids;                 // W*H   (first hit)
+    float* ts;                    // W*H   (first hit)
+    unsigned long long* counters; // 4
+    uint32_t first_pass, n_passes, pass_stride;
+    int rays_per_pixel, max_bounces, sum_mode;
+    int refill_below;             // traversal yields to the path block when fewer lanes than this traverse
+};
 
-        bool specular = random_value(rng) < m->specularStrength;
-        v3 spec_dir = V3(0.0f, 0.0f, 0.0f);
-        if (specular) {
-            spec_dir = reflect3(ray.dir, nrm);
-            diffuse = -diffuse;
-        } else if (random_value(rng) > schlick) {
-            if (random_value(rng) < m->transmission) {            // transmission (:822-847)
-                float a = -det_log(ray.prev_transmission);
-                float e = det_exp(-a * h.t);
-                v3 tc = V3(ray.prev_color[0], ray.prev_color[1], ray.prev_color[2]) * e;
-                color = color * (tc * ray.prev_color[3]);
-                if (backside) { ray.in_solid = false; ray.ior = atmo.ior; }
-                else { ray.in_solid = true; ray.ior = m->ior; }
-            } else {                                              // diffuse
-                diffuse = -diffuse;
-                if (backside) { ray.in_solid = true; ray.ior = m->ior; }
-            }
-        } else {
-            specular = true;
-            spec_dir = reflect3(ray.dir, nrm);
-            diffuse = -diffuse;
-        }
-        if (i == max_bounces) break;
-        ray.origin = hit_point;
-        if (specular) {
-            float a = m->smoothness, b = 1.0f - a;
-            ray.dir = V3(diffuse.x * b + spec_dir.x * a, diffuse.y * b + spec_dir.y * a, diffuse.z * b + spec_dir.z * a);
-            color = color * V3(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
-        } else {
-            ray.dir = diffuse;
-            color = color * V3(m->color[0], m->color[1], m->color[2]);
-        }
-        ray.prev_id = hit_id; ray.prev_mesh = hit_mesh;
-        ray.prev_color[0] = m->color[0]; ray.prev_color[1] = m->color[1];
-        ray.prev_color[2] = m->color[2]; ray.prev_color[3] = alpha;
-        ray.prev_transmission = m->transmission;
+// material index encoding: -1 atmosphere (kernel argument), [0,256) mesh, 256+i sphere i
+__device__ __forceinline__ const MatDev* material_of(const DevScene& S, int idx) {
+    return idx < 256 ? &S.mats[idx] : &S.spheres[idx - 256].material;
+}
+
+// Traversal registers of one lane.
+struct Trav {
+    int cur;          // reference being visited: interior >= 0, leaf < 0, RT_NONE = nothing
+    int sp;           // stack entries
+    int k;            // slot being tested while mode == M_TRI
+    int chunk;        // group of 32 meshes whose roots are in `mask`
+    uint32_t mask;    // roots of that group still to visit
+    bool hb;          // hitBehind for the mesh being walked
+    float best_t;
+    int best_rank;
+};
+
+// The current subtree is exhausted: take the next deferred child, else the next mesh root the
+// ray's line touches, else finish the query (mode = M_PATH).
+template <bool STATS, bool CULL>
+__device__ __forceinline__ void next_work(const DevScene& S, const float4* s_roots, int* s_stack, float* s_stack_t,
+                                          v3 org, v3 inv, int prev_mesh, bool in_solid, Trav& tv, int& mode, Counters& cnt) {
+    bool found = false;
+    while (tv.sp > 0 && !found) {                                  // deferred far children
+        tv.sp--;
+        tv.cur = s_stack[tv.sp * RT_BLOCK];
+        found = !CULL || !(s_stack_t[tv.sp * RT_BLOCK] > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS);
     }
-    return incoming;
+    while (!found) {
+        if (tv.mask) {
+            const int b = __builtin_ctz(tv.mask);
+            tv.mask &= tv.mask - 1;
+            const int j = tv.chunk * 32 + b;
+            tv.cur = __float_as_int(s_roots[2 * j].w);
+            // hitBehind for triangles of mesh j (:605-615; in a solid: same mesh only [9.6])
+            tv.hb = in_solid ? (prev_mesh == j) : (__float_as_int(s_roots[2 * j + 1].w) == 0);
+            found = true;
+        } else {
+            tv.chunk++;
+            if (tv.chunk * 32 >= S.n_meshes) { tv.cur = RT_NONE; mode = M_PATH; return; }
+            // root boxes of up to 32 meshes (LDS broadcast reads).  A leaf root is tested as the
+            // reference does (:586); for an interior root the test is an exact shortcut: child
+            // boxes nest inside it and float subtract/multiply are monotonic.
+            const int jn = min(32, S.n_meshes - tv.chunk * 32);
+            for (int b = 0; b < jn; b++) {
+                const float4 lo = s_roots[2 * (tv.chunk * 32 + b)], hi = s_roots[2 * (tv.chunk * 32 + b) + 1];
+                if (__float_as_int(lo.w) == RT_NONE) continue;
+                float ta, tb;
+                if (STATS) cnt.box++;
+                if (box_test(org, inv, lo, hi, ta, tb) && !culled<CULL>(ta, tb, tv.best_t)) tv.mask |= 1u << b;
+            }
+        }
+    }
+    if (tv.cur < 0) { mode = M_TRI; tv.k = ~tv.cur; }
+    else mode = M_NODE;
+}
+
+template <bool STATS, bool CULL, bool FIRST_HIT>
+__device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) {
+    const DevScene& S = a.scene;
+    // ---- LDS: mesh root table (2 float4 per mesh; hi.w = transparentFromBehind), then the stacks
+    float4* s_roots = s_mem;
+    const int n_root4 = 2 * S.n_meshes;
+    for (int i = threadIdx.x; i < n_root4; i += RT_BLOCK) {
+        float4 r = S.roots[i];
+        if (i & 1) r.w = __int_as_float(S.mats[i >> 1].transparentFromBehind);
+        s_roots[i] = r;
+    }
+    // per-lane stack column: entry e at s_stack[e * RT_BLOCK]; CULL builds keep the entry
+    // distance of each deferred child in a second plane so that it can be re-culled at pop
+    int* s_stack = (int*)(s_mem + n_root4) + threadIdx.x;
+    float* s_stack_t = (float*)(s_stack + (size_t)S.stack_depth * RT_BLOCK);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool live = px < a.cam.width && py < a.cam.height;
+    Counters cnt = {0, 0, 0, 0};
+
+    // ---- per-lane state -----------------------------------------------------------------
+    int mode = live ? M_PATH : M_DONE;
+    const v3 view_point = view_point_of(a.cam, px, py);
+    const size_t pix = (size_t)py * a.cam.width + px;
+    v3 col = V3(0.f, 0.f, 0.f), total = V3(0.f, 0.f, 0.f);
+    if (live && !FIRST_HIT) { const float* acc = a.accum + pix * 3; col = V3(acc[0], acc[1], acc[2]); }
+    uint32_t p = 0;            // passes finished
+    int s = 0;                 // samples of the current pass started
+    uint32_t rng = 0;
+    bool fresh = true;         // no path in flight: the path block generates a camera sample
+    v3 org = V3(0.f, 0.f, 0.f), dir = V3(0.f, 0.f, 1.f), inv = V3(0.f, 0.f, 0.f);
+    v3 thr = V3(1.f, 1.f, 1.f), inc = V3(0.f, 0.f, 0.f);
+    int prev_id = -1, prev_mat = -1, bounce = 0;
+    float ior = 1.0f;
+    bool in_solid = false;
+    Trav tv;
+    tv.cur = RT_NONE; tv.sp = 0; tv.k = 0; tv.chunk = 0; tv.mask = 0; tv.hb = false;
+    tv.best_t = 1e20f; tv.best_rank = RT_MISS_RANK;
+
+    while (true) {
+        // =============== traversal phase: NODE / TRI bursts chosen by vote ===============
+        while (true) {
+            const int cN = __popcll(__ballot(mode == M_NODE)), cT = __popcll(__ballot(mode == M_TRI));
+            if (cN + cT == 0) break;
+            if (cN + cT < a.refill_below && __popcll(__ballot(mode == M_PATH)) > 0) break;
+            if (cN >= cT) {
+                if (mode == M_NODE) {                              // :562-584, both children of `cur`
+                    const float4* n = S.nodes + 4 * (size_t)tv.cur;
+                    const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                    const int ref1 = __float_as_int(n0.w), ref2 = __float_as_int(n1.w);
+                    float t1a, t1b, t2a, t2b;
+                    bool h1 = box_test(org, inv, n0, n1, t1a, t1b);
+                    bool h2 = box_test(org, inv, n2, n3, t2a, t2b);
+                    h1 = h1 && ref1 != RT_NONE && !culled<CULL>(t1a, t1b, tv.best_t);
+                    h2 = h2 && ref2 != RT_NONE && !culled<CULL>(t2a, t2b, tv.best_t);
+                    if (STATS) cnt.box += (ref1 != RT_NONE) + (ref2 != RT_NONE);
+                    if (h1 && h2) {                                // nearer child first
+                        const bool second_near = t2a < t1a;
+                        s_stack[tv.sp * RT_BLOCK] = second_near ? ref1 : ref2;
+                        if (CULL) s_stack_t[tv.sp * RT_BLOCK] = second_near ? t1a : t2a;
+                        tv.sp++;
+                        tv.cur = second_near ? ref2 : ref1;
+                    } else {
+                        tv.cur = h1 ? ref1 : (h2 ? ref2 : RT_NONE);
+                    }
+                    if (tv.cur == RT_NONE)
+                        next_work<STATS, CULL>(S, s_roots, s_stack, s_stack_t, org, inv, prev_mat < 256 ? prev_mat : -1,
+                                               in_solid, tv, mode, cnt);
+                    else if (tv.cur < 0) { mode = M_TRI; tv.k = ~tv.cur; }
+                }
+            } else {
+                if (mode == M_TRI) {                               // one triangle of the leaf (:593-630)
+                    const float4* g = S.tri_geo + 4 * (size_t)tv.k;
+                    const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+                    if (__float_as_int(g3.z) != prev_id) {
+                        if (STATS) cnt.tri++;
+                        const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
+                        const v3 N = V3(g0.w, g1.w, g2.w);
+                        const float nd = dot3(N, dir);
+                        bool ok = !(__builtin_fabsf(nd) < 1e-6f) && !(nd > 0.0f && !tv.hb);
+                        const float t = -(dot3(N, org) + g3.x) / nd;
+                        ok = ok && !(t < 0.0f) && !(t < 1e-6f);
+                        // closer than (or tied with a later-ranked) current best; NaN t never wins
+                        ok = ok && (t < tv.best_t || (t == tv.best_t && tv.k < tv.best_rank));
+                        if (ok) {
+                            const v3 P = madd3(org, t, dir);
+                            const v3 c0 = cross3(B - A, P - A);
+                            if (!(dot3(N, c0) < 0.0f)) {
+                                const v3 c1 = cross3(C - B, P - B);
+                                if (!(dot3(N, c1) < 0.0f)) {
+                                    const v3 c2 = cross3(A - C, P - C);
+                                    if (!(dot3(N, c2) < 0.0f)) { tv.best_t = t; tv.best_rank = tv.k; }
+                                }
+                            }
+                        }
+                    }
+                    if (__float_as_int(g3.y) > 0) tv.k++;
+                    else
+                        next_work<STATS, CULL>(S, s_roots, s_stack, s_stack_t, org, inv, prev_mat < 256 ? prev_mat : -1,
+                                               in_solid, tv, mode, cnt);
+                }
+            }
+        }
+        if (__ballot(mode == M_PATH) == 0) break;                  // every lane is M_DONE
+
+        // =============== path phase: shade the finished query, start the next one ===============
+        if (mode == M_PATH) {
+            bool start = false;
+            if (!fresh) {
+                if (FIRST_HIT) {
+                    int id = -1;
+                    if (tv.best_rank != RT_MISS_RANK) {
+                        if (tv.best_rank < 0) id = -2 - (tv.best_rank - RT_SPHERE_RANK);
+                        else id = __float_as_int(S.tri_geo[4 * (size_t)tv.best_rank + 3].z);
+                    }
+                    a.ids[pix] = id;
+                    a.ts[pix] = tv.best_t;
+                    mode = M_DONE;
+                } else if (tv.best_rank == RT_MISS_RANK) {         // miss: environment light is vec3(0) (:279-282)
+                    fresh = true;
+                } else {
+                    if (STATS) cnt.hits++;
+                    // ---- rebuild the HitInfo of the winner ----
+                    const float best_t = tv.best_t;
+                    const v3 hit_point = madd3(org, best_t, dir);
+                    v3 normal;
+                    bool backside = false;
+                    int hit_id = -1, hit_mat;
+                    if (tv.best_rank < 0) {
+                        const int si = tv.best_rank - RT_SPHERE_RANK;
+                        const SphereDev& sph = S.spheres[si];
+                        normal = normalize3(hit_point - V3(sph.position[0], sph.position[1], sph.position[2]));
+                        hit_mat = 256 + si;
+                    } else {
+                        const float4* g = S.tri_geo + 4 * (size_t)tv.best_rank;
+                        const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+                        const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
+                        const v3 N = V3(g0.w, g1.w, g2.w);
+                        backside = dot3(N, dir) > 0.0f;
+                        const float area = length3(N) / 2.0f;
+                        const float w = length3(cross3(B - A, hit_point - A)) / 2.0f / area;
+                        const float u = length3(cross3(C - B, hit_point - B)) / 2.0f / area;
+                        const float v = 1.0f - u - w;
+                        const float4* nn = S.tri_nrm + 3 * (size_t)tv.best_rank;
+                        const float4 na = nn[0], nb = nn[1], nc = nn[2];
+                        normal = V3(na.x * u + nb.x * v + nc.x * w, na.y * u + nb.y * v + nc.y * w,
+                                    na.z * u + nb.z * v + nc.z * w);
+                        hit_id = __float_as_int(g3.z);
+                        hit_mat = __float_as_int(na.w);
+                    }
+                    const MatDev* m = material_of(S, hit_mat);
+                    const float alpha = m->color[3];
+                    bool ended = false, passthrough = false;
+                    if (alpha < 0.99999f) {                        // :725-736
+                        if (random_value(rng) > alpha) {
+                            passthrough = true;
+                            if (bounce == a.max_bounces) ended = true;
+                            else { org = hit_point; prev_id = hit_id; prev_mat = hit_mat; }
+                        }
+                    }
+                    if (!passthrough) {
+                        const float es = m->emissionStrength;
+                        inc = inc + V3(m->emissionColor[0] * es, m->emissionColor[1] * es, m->emissionColor[2] * es) * thr;
+                        const float nf = backside ? -1.0f : 1.0f;
+                        const v3 nrm = normal * nf;
+                        const float n2 = (in_solid && backside) ? a.atmo.ior : m->ior;
+                        const float n1 = ior;
+                        v3 diffuse = normalize3((-nrm) + random_direction(rng));
+                        const float costheta = clampf(dot3(normalize3(nrm), normalize3(-dir)), -1.0f, 1.0f);
+                        float r0 = (n1 - n2) / (n1 + n2);
+                        r0 = r0 * r0;
+                        const float om = 1.0f - costheta;
+                        const float om5 = ((om * om) * (om * om)) * om;
+                        const float schlick = r0 + (1.0f - r0) * om5;
+                        bool specular = random_value(rng) < m->specularStrength;
+                        v3 spec_dir = V3(0.0f, 0.0f, 0.0f);
+                        if (specular) {
+                            spec_dir = reflect3(dir, nrm);
+                            diffuse = -diffuse;
+                        } else if (random_value(rng) > schlick) {
+                            if (random_value(rng) < m->transmission) {   // :822-847
+                                float pc0 = a.atmo.color[0], pc1 = a.atmo.color[1], pc2 = a.atmo.color[2];
+                                float pc3 = a.atmo.color[3], ptr = a.atmo.transmission;
+                                if (prev_mat >= 0) {
+                                    const MatDev* pm = material_of(S, prev_mat);
+                                    pc0 = pm->color[0]; pc1 = pm->color[1]; pc2 = pm->color[2]; pc3 = pm->color[3];
+                                    ptr = pm->transmission;
+                                }
+                                const float at = -det_log(ptr);
+                                const float e = det_exp(-at * best_t);
+                                const v3 tc = V3(pc0, pc1, pc2) * e;
+                                thr = thr * (tc * pc3);
+                                if (backside) { in_solid = false; ior = a.atmo.ior; }
+                                else { in_solid = true; ior = m->ior; }
+                            } else {
+                                diffuse = -diffuse;
+                                if (backside) { in_solid = true; ior = m->ior; }
+                            }
+                        } else {
+                            specular = true;
+                            spec_dir = reflect3(dir, nrm);
+                            diffuse = -diffuse;
+                        }
+                        if (bounce == a.max_bounces) ended = true;
+                        else {
+                            org = hit_point;
+                            if (specular) {
+                                const float sa = m->smoothness, sb = 1.0f - sa;
+                                dir = V3(diffuse.x * sb + spec_dir.x * sa, diffuse.y * sb + spec_dir.y * sa,
+                                         diffuse.z * sb + spec_dir.z * sa);
+                                thr = thr * V3(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
+                            } else {
+                                dir = diffuse;
+                                thr = thr * V3(m->color[0], m->color[1], m->color[2]);
+                            }
+                            prev_id = hit_id;
+                            prev_mat = hit_mat;
+                        }
+                    }
+                    if (ended) fresh = true;
+                    else { bounce++; start = true; }
+                }
+                if (fresh && !FIRST_HIT) total = total + inc;      // the path is over (:989)
+            }
+            if (fresh && mode != M_DONE) {
+                if (!FIRST_HIT && s == a.rays_per_pixel) {         // a pass is complete (:1008-1021)
+                    const float rpp = (float)a.rays_per_pixel;
+                    total = V3(total.x / rpp, total.y / rpp, total.z / rpp);
+                    if (a.sum_mode) col = col + total;
+                    else {
+                        const float w = 1.0f / (float)(a.first_pass + p * a.pass_stride), om = 1.0f - w;
+                        col = V3(col.x * om + total.x * w, col.y * om + total.y * w, col.z * om + total.z * w);
+                    }
+                    total = V3(0.f, 0.f, 0.f);
+                    s = 0;
+                    p++;
+                }
+                if (p == a.n_passes) {
+                    if (!FIRST_HIT) { float* acc = a.accum + pix * 3; acc[0] = col.x; acc[1] = col.y; acc[2] = col.z; }
+                    mode = M_DONE;
+                } else {
+                    if (s == 0) rng = (uint32_t)pix + (a.first_pass + p * a.pass_stride) * 747796405u;   // :956-957
+                    // camera sample (:972-987); four draws: DoF x,y then AA x,y
+                    const float r1 = random_value(rng), r2 = random_value(rng), r3 = random_value(rng), r4 = random_value(rng);
+                    const float nearp = a.cam.view_params[2];
+                    const v3 dofo = V3(((r1 * 2.0f - 1.0f) * a.cam.dof) * nearp, ((r2 * 2.0f - 1.0f) * a.cam.dof) * nearp,
+                                       ((0.0f * 2.0f - 1.0f) * a.cam.dof) * nearp);
+                    const v3 aao = V3((r3 * 2.0f - 1.0f) * a.cam.aa, (r4 * 2.0f - 1.0f) * a.cam.aa, (0.0f * 2.0f - 1.0f) * a.cam.aa);
+                    dir = normalize3((view_point + dofo) + aao);
+                    org = V3(a.cam.cam_pos[0], a.cam.cam_pos[1], a.cam.cam_pos[2]) - dofo;
+                    prev_id = -1;
+                    prev_mat = -1;
+                    ior = a.atmo.ior;
+                    in_solid = false;
+                    thr = V3(1.f, 1.f, 1.f);
+                    inc = V3(0.f, 0.f, 0.f);
+                    bounce = 0;
+                    s++;
+                    fresh = false;
+                    start = true;
+                }
+            }
+            if (start) {                                           // begin one closest-hit query (:518-541)
+                if (STATS) cnt.rays++;
+                inv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                tv.best_t = 1e20f;
+                tv.best_rank = RT_MISS_RANK;
+                for (int i = 0; i < S.n_spheres; i++) {
+                    const SphereDev& sph = S.spheres[i];
+                    const v3 c = V3(sph.position[0], sph.position[1], sph.position[2]);
+                    const v3 oo = org - c;
+                    const float qa = dot3(dir, dir);
+                    const float qb = 2.0f * dot3(oo, dir);
+                    const float qc = dot3(oo, oo) - sph.radius * sph.radius;
+                    const float disc = qb * qb - (4.0f * qa) * qc;
+                    if (disc >= 0.0f) {
+                        const float dst = (-qb - __builtin_sqrtf(disc)) / (2.0f * qa);
+                        if (dst >= 0.0f && !(dst < 1e-6f) && dst < tv.best_t) { tv.best_t = dst; tv.best_rank = RT_SPHERE_RANK + i; }
+                    }
+                }
+                tv.sp = 0;
+                tv.cur = RT_NONE;
+                tv.chunk = -1;
+                tv.mask = 0;
+                next_work<STATS, CULL>(S, s_roots, s_stack, s_stack_t, org, inv, prev_mat < 256 ? prev_mat : -1, in_solid,
+                                       tv, mode, cnt);
+            }
+        }
+    }
+    if (STATS) {
+        unsigned long long v[4] = {cnt.rays, cnt.box, cnt.tri, cnt.hits};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            unsigned long long x = v[q];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if ((threadIdx.x & 63) == 0 && x) atomicAdd(a.counters + q, x);
+        }
+    }
 }

@@ -7,9 +7,9 @@
 //   k_refit_level device twin of the chunker refit (scripts/scenes/chunker.py:197-214),
 //                 bottom-up by tree level (exact: min/max are associative)
 //   k_pack_nodes  copies refreshed child boxes into the 64-byte traversal records
-//   k_render      ray generation + traversal + bounce loop + accumulation
-//                 (shaders/raytracer.fs.glsl main() :928-1044)
-//   k_first_hit   primary-ray closest hit only (parity probe)
+//   k_trace       ray generation + traversal + bounce loop + accumulation
+//                 (shaders/raytracer.fs.glsl main() :928-1044), wave-scheduled state machine;
+//                 FIRST_HIT instantiation = primary-ray closest hit only (parity probe)
 //   k_gather_*    read-back of posed triangles / refit boxes in the reference's std140 order
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.py).
@@ -149,99 +149,13 @@ __global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const 
     o[12] = a.x; o[13] = a.y; o[14] = a.z; o[16] = b.x; o[17] = b.y; o[18] = b.z; o[20] = c.x; o[21] = c.y; o[22] = c.z;
 }
 
-__device__ __forceinline__ void flush_counters(const Counters& c, unsigned long long* out) {
-    // per-wave reduction, then one atomic per wave and counter
-    unsigned long long v[4] = {c.rays, c.box, c.tri, c.hits};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        unsigned long long x = v[q];
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if ((threadIdx.x & 63) == 0 && x) atomicAdd(out + q, x);
-    }
-}
-
-struct RenderArgs {
-    DevScene scene;
-    DevCamera cam;
-    MatDev atmo;
-    float* accum;                 // W*H*3
-    unsigned long long* counters; // 4
-    uint32_t first_pass, n_passes, pass_stride;
-    int rays_per_pixel, max_bounces, sum_mode;
-};
-
 // One lane per pixel; a wave covers an 8x8 pixel tile, a block a 16x16 tile, so the primary
 // rays of a wave are coherent.  All passes of the launch are looped in-kernel: the pixel's
-// accumulator is read once and written once per launch.
-template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_render(RenderArgs a) {
-    __shared__ int s_stack[RT_STACK * RT_BLOCK];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    Counters cnt = {0, 0, 0, 0};
-    const bool live = px < a.cam.width && py < a.cam.height;
-    if (live) {
-        int* stack = s_stack + threadIdx.x;
-        const v3 view_point = view_point_of(a.cam, px, py);
-        float* acc = a.accum + ((size_t)py * a.cam.width + px) * 3;
-        v3 col = V3(acc[0], acc[1], acc[2]);
-        const uint32_t px_id = (uint32_t)py * (uint32_t)a.cam.width + (uint32_t)px;
-        for (uint32_t p = 0; p < a.n_passes; p++) {
-            const uint32_t pass = a.first_pass + p * a.pass_stride;
-            uint32_t rng = px_id + pass * 747796405u;          // :956-957
-            v3 total = V3(0.0f, 0.0f, 0.0f);
-            for (int s = 0; s < a.rays_per_pixel; s++) {
-                PathState ray;
-                new_sample_ray(a.cam, a.atmo, view_point, rng, ray);
-                total = total + trace_path<STATS>(a.scene, a.atmo, ray, rng, a.max_bounces, stack, cnt);
-            }
-            const float rpp = (float)a.rays_per_pixel;
-            total = V3(total.x / rpp, total.y / rpp, total.z / rpp);   // :1008
-            if (a.sum_mode) {
-                col = col + total;
-            } else {                                                   // running mean :1015-1021
-                const float w = 1.0f / (float)pass, om = 1.0f - w;
-                col = V3(col.x * om + total.x * w, col.y * om + total.y * w, col.z * om + total.z * w);
-            }
-        }
-        acc[0] = col.x; acc[1] = col.y; acc[2] = col.z;
-    }
-    if (STATS) flush_counters(cnt, a.counters);
-}
-
-struct FirstHitArgs {
-    DevScene scene;
-    DevCamera cam;
-    MatDev atmo;
-    int32_t* ids;
-    float* ts;
-    unsigned long long* counters;
-    uint32_t pass;
-};
-
-template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_first_hit(FirstHitArgs a) {
-    __shared__ int s_stack[RT_STACK * RT_BLOCK];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    Counters cnt = {0, 0, 0, 0};
-    if (px < a.cam.width && py < a.cam.height) {
-        uint32_t rng = (uint32_t)py * (uint32_t)a.cam.width + (uint32_t)px + a.pass * 747796405u;
-        PathState ray;
-        new_sample_ray(a.cam, a.atmo, view_point_of(a.cam, px, py), rng, ray);
-        Hit h = closest_hit<STATS>(a.scene, ray.origin, ray.dir, -1, -1, false, s_stack + threadIdx.x, cnt);
-        int id = -1;
-        if (h.rank != 0x7fffffff) {
-            if (h.rank < 0) id = -2 - (h.rank - RT_SPHERE_RANK);
-            else id = __float_as_int(a.scene.tri_geo[4 * (size_t)h.rank + 3].z);
-        }
-        size_t o = (size_t)py * a.cam.width + px;
-        a.ids[o] = id;
-        a.ts[o] = h.t;
-    }
-    if (STATS) flush_counters(cnt, a.counters);
+// accumulator is read once and written once per launch.  Dynamic LDS: mesh root table + stacks.
+template <bool STATS, bool CULL, bool FIRST_HIT>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(TraceArgs a) {
+    extern __shared__ float4 s_mem[];
+    trace_pixels<STATS, CULL, FIRST_HIT>(a, s_mem);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -296,7 +210,10 @@ struct rt_ctx {
     std::vector<Std140Node> h_nodes;      // topology as uploaded (for rt_read_nodes48)
     MatDev atmo{};
     int n_tris = 0, n_slots = 0, n_meshes = 0, n_nodes = 0, n_visit = 0, n_rec = 0, n_spheres = 0;
+    int stack_depth = 1;
     bool have_scene = false, have_cam = false, prep_pending = false;
+    bool cull = false;                    // conservative distance culling (rt_set_cull)
+    int refill_below = 40;                // lanes still traversing below which a wave shades/refills
     // camera / image
     DevCamera cam{};
     DevBuf<float> accum_own;
@@ -387,7 +304,41 @@ DevScene scene_view(const rt_ctx* c) {
     DevScene s;
     s.tri_geo = c->geo.p; s.tri_nrm = c->nrm.p; s.nodes = c->nodes.p; s.roots = c->roots.p;
     s.mats = c->mats.p; s.spheres = c->spheres.p; s.n_meshes = c->n_meshes; s.n_spheres = c->n_spheres;
+    s.stack_depth = c->stack_depth;
     return s;
+}
+
+void fill_args(const rt_ctx* c, TraceArgs& a) {
+    a.scene = scene_view(c);
+    a.cam = c->cam;
+    a.atmo = c->atmo;
+    a.accum = c->accum;
+    a.ids = nullptr;
+    a.ts = nullptr;
+    a.counters = c->counters.p;
+    a.refill_below = c->refill_below;
+}
+
+template <bool STATS, bool CULL, bool FIRST>
+void launch_one(const rt_ctx* c, const TraceArgs& a) {
+    const dim3 grid((c->cam.width + 15) / 16, (c->cam.height + 15) / 16), block(RT_BLOCK);
+    // dynamic LDS: root table + per-lane stack (+ the entry-distance plane when culling)
+    const size_t lds = (size_t)2 * c->n_meshes * sizeof(float4) + (size_t)c->stack_depth * RT_BLOCK * 4 * (CULL ? 2 : 1);
+    hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST>), grid, block, lds, c->stream, a);
+}
+
+void launch_trace(const rt_ctx* c, const TraceArgs& a, bool first_hit) {
+    const int key = (c->stats_on ? 4 : 0) | (c->cull ? 2 : 0) | (first_hit ? 1 : 0);
+    switch (key) {
+    case 0: launch_one<false, false, false>(c, a); break;
+    case 1: launch_one<false, false, true>(c, a); break;
+    case 2: launch_one<false, true, false>(c, a); break;
+    case 3: launch_one<false, true, true>(c, a); break;
+    case 4: launch_one<true, false, false>(c, a); break;
+    case 5: launch_one<true, false, true>(c, a); break;
+    case 6: launch_one<true, true, false>(c, a); break;
+    default: launch_one<true, true, true>(c, a); break;
+    }
 }
 
 int check_ready(rt_ctx* c) {
@@ -428,6 +379,7 @@ int rt_create(int device, rt_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
     c->stream = c->own_stream;
+    if (const char* e = getenv("RT_REFILL_BELOW")) c->refill_below = std::max(1, std::min(64, atoi(e)));
     if (c->counters.alloc(4) != hipSuccess || hipMemsetAsync(c->counters.p, 0, 32, c->stream) != hipSuccess) {
         (void)hipStreamDestroy(c->own_stream);
         delete c;
@@ -595,6 +547,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     c->h_xf.assign(16 * (size_t)std::max(n_meshes, 1), 0.f);
     c->h_dirty.assign((size_t)std::max(n_meshes, 1), 2);        // 2 = copy rest pose as given
     c->level_off = level_off;
+    c->stack_depth = max_depth + 1;
     c->node_first_visit = first_visit;
     c->h_nodes.assign(nodes, nodes + n_nodes);
     c->have_scene = true;
@@ -744,17 +697,12 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
     if (flags == RT_ACCUM_MEAN && stride != 1) return fail(c, RT_E_ARG, "running mean needs pass_stride 1");
     HIPCK(c, hipSetDevice(c->device));
     if ((rc = run_prep(c))) return rc;
-    RenderArgs a;
-    a.scene = scene_view(c);
-    a.cam = c->cam;
-    a.atmo = c->atmo;
-    a.accum = c->accum;
-    a.counters = c->counters.p;
+    TraceArgs a;
+    fill_args(c, a);
     a.pass_stride = stride;
     a.rays_per_pixel = rpp;
     a.max_bounces = max_bounces;
     a.sum_mode = (flags == RT_ACCUM_SUM);
-    const dim3 grid((c->cam.width + 15) / 16, (c->cam.height + 15) / 16), block(RT_BLOCK);
     // bound the length of one launch: at most ~2^27 camera samples per launch
     const uint64_t per_pass = (uint64_t)c->cam.width * c->cam.height * (uint64_t)rpp;
     uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (1ull << 27) / std::max<uint64_t>(per_pass, 1));
@@ -765,8 +713,7 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
     for (uint32_t done = 0; done < n_passes; done += chunk) {
         a.first_pass = first + done * stride;
         a.n_passes = std::min(chunk, n_passes - done);
-        if (c->stats_on) hipLaunchKernelGGL(k_render<true>, grid, block, 0, c->stream, a);
-        else hipLaunchKernelGGL(k_render<false>, grid, block, 0, c->stream, a);
+        launch_trace(c, a, false);
         c->st.launches++;
     }
     HIPCK(c, hipEventRecord(e1, c->stream));
@@ -789,21 +736,21 @@ int rt_first_hit(rt_ctx* c, uint32_t pass, int32_t* ids, float* ts) {
     DevBuf<float> d_ts;
     HIPCK(c, d_ids.alloc(n));
     if (d_ts.alloc(n) != hipSuccess) { d_ids.release(); return fail(c, RT_E_DEVICE, "first_hit: out of device memory"); }
-    FirstHitArgs a;
-    a.scene = scene_view(c);
-    a.cam = c->cam;
-    a.atmo = c->atmo;
+    TraceArgs a;
+    fill_args(c, a);
     a.ids = d_ids.p;
     a.ts = d_ts.p;
-    a.counters = c->counters.p;
-    a.pass = pass;
-    const dim3 grid((c->cam.width + 15) / 16, (c->cam.height + 15) / 16), block(RT_BLOCK);
+    a.first_pass = pass;
+    a.n_passes = 1;
+    a.pass_stride = 1;
+    a.rays_per_pixel = 1;
+    a.max_bounces = 0;
+    a.sum_mode = 0;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, c->stream);
-    if (c->stats_on) hipLaunchKernelGGL(k_first_hit<true>, grid, block, 0, c->stream, a);
-    else hipLaunchKernelGGL(k_first_hit<false>, grid, block, 0, c->stream, a);
+    launch_trace(c, a, true);
     (void)hipEventRecord(e1, c->stream);
     c->pending_events.push_back({e0, e1});
     c->st.launches++;
@@ -836,6 +783,12 @@ int rt_read_mean(rt_ctx* c, float* out) {
         const size_t n = (size_t)c->cam.width * c->cam.height * 3;
         for (size_t i = 0; i < n; i++) out[i] = out[i] / d;
     }
+    return RT_OK;
+}
+
+int rt_set_cull(rt_ctx* c, int enable) {
+    if (!c) return RT_E_ARG;
+    c->cull = enable != 0;
     return RT_OK;
 }
 

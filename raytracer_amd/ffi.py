@@ -59,6 +59,7 @@ _SIGNATURES = {
     "rt_read_accum": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64)]),
     "rt_read_mean": (C.c_int, [_vp, _vp]),
     "rt_set_accum_passes": (C.c_int, [_vp, C.c_uint64]),
+    "rt_set_cull": (C.c_int, [_vp, C.c_int]),
     "rt_enable_stats": (C.c_int, [_vp, C.c_int]),
     "rt_reset_stats": (C.c_int, [_vp]),
     "rt_get_stats": (C.c_int, [_vp, C.POINTER(RtStats)]),
@@ -215,6 +216,9 @@ class RtContext:
         return out
 
     # -- counters ------------------------------------------------------------------------------------
+    def set_cull(self, on: bool) -> None:
+        self._ck(self.lib.dll.rt_set_cull(self._h, int(on)), "rt_set_cull")
+
     def enable_stats(self, on: bool = True) -> None:
         self._ck(self.lib.dll.rt_enable_stats(self._h, int(on)), "rt_enable_stats")
 
