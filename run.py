@@ -1,0 +1,32 @@
+"""Entry point with the reference's shape (run.py:1-10): pick a scene module, start the app.
+
+    python run.py [--frames N] [--height H] [--passes P] [--bounces B]
+
+Headless: renders N animation frames of the Suzanne scene on GPU 0 and writes PNG + float32
+dumps under renders/RayTracerDynamic/<timestamp>/ at the reference's cadence."""
+import argparse
+
+import raytracer_amd.scripts.application as application
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=1)
+    ap.add_argument("--height", type=int, default=1080 // 4)
+    ap.add_argument("--passes", type=int, default=None, help="override the scene's passes_per_frame")
+    ap.add_argument("--bounces", type=int, default=None)
+    args = ap.parse_args()
+
+    from raytracer_amd.scripts.animate import FrameAnimation
+    from raytracer_amd.scripts.scenes import final_scene_numba
+
+    application.set_scene(final_scene_numba)
+    application.HEADLESS = True
+    if args.passes is not None or args.bounces is not None:
+        def override(cam, i):
+            if args.passes is not None:
+                cam.passes_per_frame = args.passes
+            if args.bounces is not None:
+                cam.bounces_per_ray = args.bounces
+        final_scene_numba.scene.animations.append(FrameAnimation(final_scene_numba.scene.cam, override))
+    app = application.Application(render_height=args.height, max_frames=args.frames)
+    app.start()
