@@ -60,6 +60,9 @@ typedef struct rt_stats_t {
     uint64_t samples;     /* camera samples started (pixels * rays_per_pixel * passes)    */
     double kernel_ms;     /* device time of those launches (hipEvent), 0 for the oracle   */
     uint64_t launches;
+    /* wave scheduler statistics of counting launches (0 for the oracle): block executions and
+     * the lanes active in them: {node_steps, node_lanes, tri_steps, tri_lanes, path_steps, path_lanes} */
+    uint64_t sched[6];
 } rt_stats_t;
 
 /* replaces: ProgramABC.__init__/initialise creating the GL context (application.py:499-575) */

@@ -79,6 +79,8 @@ struct DevCamera {
 };
 
 struct Counters { unsigned long long rays, box, tri, hits; };
+// wave-level scheduler statistics (STATS builds): executions of each block and lanes active in them
+struct SchedStats { unsigned long long node_steps, node_lanes, tri_steps, tri_lanes, path_steps, path_lanes; };
 
 // The reference's slab test, comparison for comparison (NaN compares false, no t >= 0 test).
 // On a hit, [tmin, tmax] is the entry/exit interval the reference ends up with.
@@ -106,6 +108,16 @@ __device__ __forceinline__ bool culled(float tmin, float tmax, float best_t) {
     if (!CULL) return false;
     return (tmax < -RT_CULL_ABS) || (tmin > fma_(best_t, RT_CULL_REL, best_t) + RT_CULL_ABS);
 }
+
+// Entry distance of a deferred child, kept in 16 bits (LDS is what limits occupancy here):
+// the top half of the binary32 pattern, rounded DOWN so that the re-check at pop can only
+// cull less than the full value would.  NaN stays NaN (never culls).
+__device__ __forceinline__ unsigned short pack_dist(float t) {
+    uint32_t u = __float_as_uint(t);
+    if ((u >> 31) && (u & 0xffffu) && (u & 0x7f800000u) != 0x7f800000u) u += 0x10000u;   // negative: larger magnitude
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float unpack_dist(unsigned short h) { return __uint_as_float((uint32_t)h << 16); }
 
 // fragPosition -> world-space view point (raytracer.fs.glsl:961-962, raytracer.vs.glsl:6-9)
 __device__ __forceinline__ v3 view_point_of(const DevCamera& cam, int px, int py) {
@@ -158,13 +170,13 @@ struct Trav {
 // The current subtree is exhausted: take the next deferred child, else the next mesh root the
 // ray's line touches, else finish the query (mode = M_PATH).
 template <bool STATS, bool CULL>
-__device__ __forceinline__ void next_work(const DevScene& S, const float4* s_roots, int* s_stack, float* s_stack_t,
+__device__ __forceinline__ void next_work(const DevScene& S, const float4* s_roots, int* s_stack, unsigned short* s_stack_t,
                                           v3 org, v3 inv, int prev_mesh, bool in_solid, Trav& tv, int& mode, Counters& cnt) {
     bool found = false;
     while (tv.sp > 0 && !found) {                                  // deferred far children
         tv.sp--;
         tv.cur = s_stack[tv.sp * RT_BLOCK];
-        found = !CULL || !(s_stack_t[tv.sp * RT_BLOCK] > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS);
+        found = !CULL || !(unpack_dist(s_stack_t[tv.sp * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS);
     }
     while (!found) {
         if (tv.mask) {
@@ -209,7 +221,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     // per-lane stack column: entry e at s_stack[e * RT_BLOCK]; CULL builds keep the entry
     // distance of each deferred child in a second plane so that it can be re-culled at pop
     int* s_stack = (int*)(s_mem + n_root4) + threadIdx.x;
-    float* s_stack_t = (float*)(s_stack + (size_t)S.stack_depth * RT_BLOCK);
+    unsigned short* s_stack_t = (unsigned short*)((int*)(s_mem + n_root4) + (size_t)S.stack_depth * RT_BLOCK) + threadIdx.x;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -217,6 +229,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
     const bool live = px < a.cam.width && py < a.cam.height;
     Counters cnt = {0, 0, 0, 0};
+    SchedStats sch = {0, 0, 0, 0, 0, 0};
 
     // ---- per-lane state -----------------------------------------------------------------
     int mode = live ? M_PATH : M_DONE;
@@ -243,6 +256,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             const int cN = __popcll(__ballot(mode == M_NODE)), cT = __popcll(__ballot(mode == M_TRI));
             if (cN + cT == 0) break;
             if (cN + cT < a.refill_below && __popcll(__ballot(mode == M_PATH)) > 0) break;
+            if (STATS) { if (cN >= cT) { sch.node_steps++; sch.node_lanes += cN; } else { sch.tri_steps++; sch.tri_lanes += cT; } }
             if (cN >= cT) {
                 if (mode == M_NODE) {                              // :562-584, both children of `cur`
                     const float4* n = S.nodes + 4 * (size_t)tv.cur;
@@ -257,7 +271,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     if (h1 && h2) {                                // nearer child first
                         const bool second_near = t2a < t1a;
                         s_stack[tv.sp * RT_BLOCK] = second_near ? ref1 : ref2;
-                        if (CULL) s_stack_t[tv.sp * RT_BLOCK] = second_near ? t1a : t2a;
+                        if (CULL) s_stack_t[tv.sp * RT_BLOCK] = pack_dist(second_near ? t1a : t2a);
                         tv.sp++;
                         tv.cur = second_near ? ref2 : ref1;
                     } else {
@@ -304,6 +318,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
         if (__ballot(mode == M_PATH) == 0) break;                  // every lane is M_DONE
 
         // =============== path phase: shade the finished query, start the next one ===============
+        if (STATS) { sch.path_steps++; sch.path_lanes += __popcll(__ballot(mode == M_PATH)); }
         if (mode == M_PATH) {
             bool start = false;
             if (!fresh) {
@@ -494,6 +509,11 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             unsigned long long x = v[q];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
             if ((threadIdx.x & 63) == 0 && x) atomicAdd(a.counters + q, x);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned long long w[6] = {sch.node_steps, sch.node_lanes, sch.tri_steps, sch.tri_lanes, sch.path_steps, sch.path_lanes};
+#pragma unroll
+            for (int q = 0; q < 6; q++) atomicAdd(a.counters + 4 + q, w[q]);
         }
     }
 }

@@ -152,8 +152,11 @@ __global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const 
 // One lane per pixel; a wave covers an 8x8 pixel tile, a block a 16x16 tile, so the primary
 // rays of a wave are coherent.  All passes of the launch are looped in-kernel: the pixel's
 // accumulator is read once and written once per launch.  Dynamic LDS: mesh root table + stacks.
+#ifndef RT_WAVES
+#define RT_WAVES 5
+#endif
 template <bool STATS, bool CULL, bool FIRST_HIT>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(TraceArgs a) {
+__global__ __launch_bounds__(RT_BLOCK, RT_WAVES) void k_trace(TraceArgs a) {
     extern __shared__ float4 s_mem[];
     trace_pixels<STATS, CULL, FIRST_HIT>(a, s_mem);
 }
@@ -323,7 +326,7 @@ template <bool STATS, bool CULL, bool FIRST>
 void launch_one(const rt_ctx* c, const TraceArgs& a) {
     const dim3 grid((c->cam.width + 15) / 16, (c->cam.height + 15) / 16), block(RT_BLOCK);
     // dynamic LDS: root table + per-lane stack (+ the entry-distance plane when culling)
-    const size_t lds = (size_t)2 * c->n_meshes * sizeof(float4) + (size_t)c->stack_depth * RT_BLOCK * 4 * (CULL ? 2 : 1);
+    const size_t lds = (size_t)2 * c->n_meshes * sizeof(float4) + (size_t)c->stack_depth * RT_BLOCK * (CULL ? 6 : 4);
     hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST>), grid, block, lds, c->stream, a);
 }
 
@@ -380,7 +383,7 @@ int rt_create(int device, rt_ctx** out) {
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
     c->stream = c->own_stream;
     if (const char* e = getenv("RT_REFILL_BELOW")) c->refill_below = std::max(1, std::min(64, atoi(e)));
-    if (c->counters.alloc(4) != hipSuccess || hipMemsetAsync(c->counters.p, 0, 32, c->stream) != hipSuccess) {
+    if (c->counters.alloc(16) != hipSuccess || hipMemsetAsync(c->counters.p, 0, 128, c->stream) != hipSuccess) {
         (void)hipStreamDestroy(c->own_stream);
         delete c;
         return RT_E_DEVICE;
@@ -803,7 +806,7 @@ int rt_reset_stats(rt_ctx* c) {
     HIPCK(c, hipSetDevice(c->device));
     int rc = resolve_events(c);
     if (rc) return rc;
-    HIPCK(c, hipMemsetAsync(c->counters.p, 0, 32, c->stream));
+    HIPCK(c, hipMemsetAsync(c->counters.p, 0, 128, c->stream));
     c->st = rt_stats_t{};
     return RT_OK;
 }
@@ -813,10 +816,11 @@ int rt_get_stats(rt_ctx* c, rt_stats_t* o) {
     HIPCK(c, hipSetDevice(c->device));
     int rc = resolve_events(c);
     if (rc) return rc;
-    unsigned long long h[4];
-    HIPCK(c, hipMemcpyAsync(h, c->counters.p, 32, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long h[16];
+    HIPCK(c, hipMemcpyAsync(h, c->counters.p, 128, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     c->st.rays = h[0]; c->st.box_tests = h[1]; c->st.tri_tests = h[2]; c->st.shaded_hits = h[3];
+    for (int q = 0; q < 6; q++) c->st.sched[q] = h[4 + q];
     *o = c->st;
     return RT_OK;
 }

@@ -26,10 +26,13 @@ class RtStats(C.Structure):
         ("samples", C.c_uint64),
         ("kernel_ms", C.c_double),
         ("launches", C.c_uint64),
+        ("sched", C.c_uint64 * 6),
     ]
 
     def as_dict(self) -> dict:
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["sched"] = list(self.sched)
+        return d
 
 
 class RtError(RuntimeError):

@@ -13,13 +13,20 @@ w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 108
 bounces = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 sc = S.build()
 sc.animate_frame(0)
-ctx = ffi.RtLib().create(0)
+import os
+ctx = ffi.RtLib(os.environ.get('RT_LIB') or None).create(0)
 ctx.load_scene(sc)
 ctx.load_camera(sc.cam)
 ctx.resize(w, h)
 import os
 ctx.set_cull(os.environ.get('RT_CULL', '0') == '1')
+if os.environ.get('RT_STATS') == '1':
+    ctx.enable_stats(True)
 ctx.render(1, passes, 1, 1, bounces, 0)
 ctx.sync()
 st = ctx.stats()
+if os.environ.get("RT_STATS") == "1":
+    r = st["rays"]; sc = st["sched"]
+    print(f"rays={r} B/ray={st['box_tests']/r:.2f} T/ray={st['tri_tests']/r:.2f} H/ray={st['shaded_hits']/r:.3f}")
+    print(f"node steps/ray={sc[1]/r:.2f} avg lanes={sc[1]/max(sc[0],1):.1f}; tri steps/ray={sc[3]/r:.2f} avg lanes={sc[3]/max(sc[2],1):.1f}; path steps/ray={sc[5]/r:.2f} avg lanes={sc[5]/max(sc[4],1):.1f}")
 print(f"passes={passes} {w}x{h} bounces={bounces} kernel_ms={st['kernel_ms']:.3f}")
