@@ -102,6 +102,23 @@ __device__ __forceinline__ bool box_test(v3 o, v3 inv, float4 lo, float4 hi, flo
     return hit;
 }
 
+// Same test for rays whose 1/d components are all finite (every ray except those with an
+// exactly zero direction component): no slab value can then be NaN (finite*finite, or
+// +-inf from overflow), and for non-NaN values the reference's compare-and-swap ladder is
+// exactly  max(entry_x, entry_y, entry_z) <= min(exit_x, exit_y, exit_z)  with per-axis
+// entry/exit = min/max of the two slab values (proof: DESIGN.md 5).  v_min/v_max/v_max3/v_min3
+// issue in 2 cycles where a v_cmp + v_cndmask pair takes 8 (tools/ubench/valu_rate.hip).
+__device__ __forceinline__ bool box_test_finite(v3 o, v3 inv, float4 lo, float4 hi, float& tmin_out, float& tmax_out) {
+    const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+    const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+    const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    tmin_out = tmin;
+    tmax_out = tmax;
+    return tmin <= tmax;
+}
+
 // true when the culling band allows skipping a box with interval [tmin,tmax]; NaN never culls
 template <bool CULL>
 __device__ __forceinline__ bool culled(float tmin, float tmax, float best_t) {
@@ -167,44 +184,60 @@ struct Trav {
     int best_rank;
 };
 
-// The current subtree is exhausted: take the next deferred child, else the next mesh root the
-// ray's line touches, else finish the query (mode = M_PATH).
+// Root boxes of one group of up to 32 meshes (LDS broadcast reads) -> bit mask of the meshes whose
+// root box the ray's line touches.  A leaf root is tested as the reference does (:586); for an
+// interior root the test is an exact shortcut: child boxes nest inside it and float
+// subtract/multiply are monotonic, so no child test could pass when the root test fails.
+template <bool STATS, bool CULL>
+__device__ __forceinline__ uint32_t root_mask(const DevScene& S, const float4* s_roots, int chunk, v3 org, v3 inv, float best_t,
+                                              Counters& cnt) {
+    uint32_t mask = 0;
+    const int jn = min(32, S.n_meshes - chunk * 32);
+    // wave-uniform choice of the slab-test form (see box_test_finite)
+    const bool all_finite = __ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0;
+    for (int b = 0; b < jn; b++) {
+        const float4 lo = s_roots[2 * (chunk * 32 + b)], hi = s_roots[2 * (chunk * 32 + b) + 1];
+        float ta, tb;
+        const bool h = all_finite ? box_test_finite(org, inv, lo, hi, ta, tb) : box_test(org, inv, lo, hi, ta, tb);
+        const bool take = __float_as_int(lo.w) != RT_NONE && h && !culled<CULL>(ta, tb, best_t);
+        if (STATS) cnt.box += __float_as_int(lo.w) != RT_NONE;
+        mask |= take ? (1u << b) : 0u;
+    }
+    return mask;
+}
+
+// The current subtree is exhausted: ONE action, no loops (divergent loops cost a chain of scalar
+// mask instructions per trip, and the scalar unit is shared by the CU's four SIMDs): pop one
+// deferred child, else take the next mesh root, else finish the query (mode = M_PATH).  When the
+// action yields nothing to visit (popped child now beyond the best hit, or a new group of roots
+// was only just tested) the lane stays in M_NODE with cur = RT_NONE and comes back here.
 template <bool STATS, bool CULL>
 __device__ __forceinline__ void next_work(const DevScene& S, const float4* s_roots, int* s_stack, unsigned short* s_stack_t,
                                           v3 org, v3 inv, int prev_mesh, bool in_solid, Trav& tv, int& mode, Counters& cnt) {
-    bool found = false;
-    while (tv.sp > 0 && !found) {                                  // deferred far children
+    int cur = RT_NONE;
+    if (tv.sp > 0) {                                               // deferred far child
         tv.sp--;
-        tv.cur = s_stack[tv.sp * RT_BLOCK];
-        found = !CULL || !(unpack_dist(s_stack_t[tv.sp * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS);
+        cur = s_stack[tv.sp * RT_BLOCK];
+        if (CULL && unpack_dist(s_stack_t[tv.sp * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS) cur = RT_NONE;
+    } else if (tv.mask) {                                          // next mesh root
+        const int b = __builtin_ctz(tv.mask);
+        tv.mask &= tv.mask - 1;
+        const int j = tv.chunk * 32 + b;
+        cur = __float_as_int(s_roots[2 * j].w);
+        // hitBehind for triangles of mesh j (:605-615; in a solid: same mesh only [9.6])
+        tv.hb = in_solid ? (prev_mesh == j) : (__float_as_int(s_roots[2 * j + 1].w) == 0);
+    } else if ((tv.chunk + 1) * 32 >= S.n_meshes) {
+        tv.cur = RT_NONE;
+        mode = M_PATH;
+        return;
+    } else {                                                       // more than 32 meshes: next group of roots
+        tv.chunk++;
+        tv.mask = root_mask<STATS, CULL>(S, s_roots, tv.chunk, org, inv, tv.best_t, cnt);
     }
-    while (!found) {
-        if (tv.mask) {
-            const int b = __builtin_ctz(tv.mask);
-            tv.mask &= tv.mask - 1;
-            const int j = tv.chunk * 32 + b;
-            tv.cur = __float_as_int(s_roots[2 * j].w);
-            // hitBehind for triangles of mesh j (:605-615; in a solid: same mesh only [9.6])
-            tv.hb = in_solid ? (prev_mesh == j) : (__float_as_int(s_roots[2 * j + 1].w) == 0);
-            found = true;
-        } else {
-            tv.chunk++;
-            if (tv.chunk * 32 >= S.n_meshes) { tv.cur = RT_NONE; mode = M_PATH; return; }
-            // root boxes of up to 32 meshes (LDS broadcast reads).  A leaf root is tested as the
-            // reference does (:586); for an interior root the test is an exact shortcut: child
-            // boxes nest inside it and float subtract/multiply are monotonic.
-            const int jn = min(32, S.n_meshes - tv.chunk * 32);
-            for (int b = 0; b < jn; b++) {
-                const float4 lo = s_roots[2 * (tv.chunk * 32 + b)], hi = s_roots[2 * (tv.chunk * 32 + b) + 1];
-                if (__float_as_int(lo.w) == RT_NONE) continue;
-                float ta, tb;
-                if (STATS) cnt.box++;
-                if (box_test(org, inv, lo, hi, ta, tb) && !culled<CULL>(ta, tb, tv.best_t)) tv.mask |= 1u << b;
-            }
-        }
-    }
-    if (tv.cur < 0) { mode = M_TRI; tv.k = ~tv.cur; }
-    else mode = M_NODE;
+    tv.cur = cur;
+    const bool leaf = cur < 0 && cur != RT_NONE;
+    mode = leaf ? M_TRI : M_NODE;
+    tv.k = leaf ? ~cur : tv.k;
 }
 
 template <bool STATS, bool CULL, bool FIRST_HIT>
@@ -258,13 +291,22 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             if (cN + cT < a.refill_below && __popcll(__ballot(mode == M_PATH)) > 0) break;
             if (STATS) { if (cN >= cT) { sch.node_steps++; sch.node_lanes += cN; } else { sch.tri_steps++; sch.tri_lanes += cT; } }
             if (cN >= cT) {
-                if (mode == M_NODE) {                              // :562-584, both children of `cur`
+                if (mode == M_NODE && tv.cur == RT_NONE) {         // nothing in hand: fetch the next piece of work
+                    next_work<STATS, CULL>(S, s_roots, s_stack, s_stack_t, org, inv, prev_mat < 256 ? prev_mat : -1,
+                                           in_solid, tv, mode, cnt);
+                } else if (mode == M_NODE) {                       // :562-584, both children of `cur`
                     const float4* n = S.nodes + 4 * (size_t)tv.cur;
                     const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
                     const int ref1 = __float_as_int(n0.w), ref2 = __float_as_int(n1.w);
                     float t1a, t1b, t2a, t2b;
-                    bool h1 = box_test(org, inv, n0, n1, t1a, t1b);
-                    bool h2 = box_test(org, inv, n2, n3, t2a, t2b);
+                    bool h1, h2;
+                    if (__ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0) {
+                        h1 = box_test_finite(org, inv, n0, n1, t1a, t1b);
+                        h2 = box_test_finite(org, inv, n2, n3, t2a, t2b);
+                    } else {                                       // a lane has an exactly zero direction component
+                        h1 = box_test(org, inv, n0, n1, t1a, t1b);
+                        h2 = box_test(org, inv, n2, n3, t2a, t2b);
+                    }
                     h1 = h1 && ref1 != RT_NONE && !culled<CULL>(t1a, t1b, tv.best_t);
                     h2 = h2 && ref2 != RT_NONE && !culled<CULL>(t2a, t2b, tv.best_t);
                     if (STATS) cnt.box += (ref1 != RT_NONE) + (ref2 != RT_NONE);
@@ -286,27 +328,26 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 if (mode == M_TRI) {                               // one triangle of the leaf (:593-630)
                     const float4* g = S.tri_geo + 4 * (size_t)tv.k;
                     const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-                    if (__float_as_int(g3.z) != prev_id) {
-                        if (STATS) cnt.tri++;
-                        const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
-                        const v3 N = V3(g0.w, g1.w, g2.w);
-                        const float nd = dot3(N, dir);
-                        bool ok = !(__builtin_fabsf(nd) < 1e-6f) && !(nd > 0.0f && !tv.hb);
-                        const float t = -(dot3(N, org) + g3.x) / nd;
-                        ok = ok && !(t < 0.0f) && !(t < 1e-6f);
-                        // closer than (or tied with a later-ranked) current best; NaN t never wins
-                        ok = ok && (t < tv.best_t || (t == tv.best_t && tv.k < tv.best_rank));
-                        if (ok) {
-                            const v3 P = madd3(org, t, dir);
-                            const v3 c0 = cross3(B - A, P - A);
-                            if (!(dot3(N, c0) < 0.0f)) {
-                                const v3 c1 = cross3(C - B, P - B);
-                                if (!(dot3(N, c1) < 0.0f)) {
-                                    const v3 c2 = cross3(A - C, P - C);
-                                    if (!(dot3(N, c2) < 0.0f)) { tv.best_t = t; tv.best_rank = tv.k; }
-                                }
-                            }
-                        }
+                    // all rejects are folded into one predicate and the three edge tests run together:
+                    // one divergent region instead of five nested ones (scalar-unit pressure)
+                    const bool tested = __float_as_int(g3.z) != prev_id;
+                    if (STATS) cnt.tri += tested;
+                    const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
+                    const v3 N = V3(g0.w, g1.w, g2.w);
+                    const float nd = dot3(N, dir);
+                    const float t = -(dot3(N, org) + g3.x) / nd;
+                    bool ok = tested && !(__builtin_fabsf(nd) < 1e-6f) && !(nd > 0.0f && !tv.hb);
+                    ok = ok && !(t < 1e-6f);                        // covers the reference's `t < 0` reject too
+                    // closer than (or tied with a later-ranked) current best; NaN t never wins
+                    ok = ok && (t < tv.best_t || (t == tv.best_t && tv.k < tv.best_rank));
+                    if (ok) {
+                        const v3 P = madd3(org, t, dir);
+                        const float e0 = dot3(N, cross3(B - A, P - A));
+                        const float e1 = dot3(N, cross3(C - B, P - B));
+                        const float e2 = dot3(N, cross3(A - C, P - C));
+                        const bool inside = !(e0 < 0.0f) && !(e1 < 0.0f) && !(e2 < 0.0f);
+                        tv.best_t = inside ? t : tv.best_t;
+                        tv.best_rank = inside ? tv.k : tv.best_rank;
                     }
                     if (__float_as_int(g3.y) > 0) tv.k++;
                     else
@@ -495,8 +536,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 }
                 tv.sp = 0;
                 tv.cur = RT_NONE;
-                tv.chunk = -1;
-                tv.mask = 0;
+                tv.chunk = 0;
+                tv.mask = root_mask<STATS, CULL>(S, s_roots, 0, org, inv, tv.best_t, cnt);
                 next_work<STATS, CULL>(S, s_roots, s_stack, s_stack_t, org, inv, prev_mat < 256 ? prev_mat : -1, in_solid,
                                        tv, mode, cnt);
             }
