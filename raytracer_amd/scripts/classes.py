@@ -122,12 +122,15 @@ class Sphere:
         self.radius = radius
         self.material = material
 
-    def tobytes(self) -> bytes:
+    def as_record(self) -> np.ndarray:
         r = np.zeros((), dtype=SPHERE_DTYPE)
         r["position"] = np.asarray(self.pos, dtype=np.float64)
         r["radius"] = self.radius
         r["material"] = self.material.as_record()
-        return r.tobytes()
+        return r
+
+    def tobytes(self) -> bytes:
+        return self.as_record().tobytes()
 
 
 class Mesh:
