@@ -2,7 +2,7 @@
 """bench.py - Mrays/s of the rendering hot path on BASELINE.json configs[1]:
 Suzanne room, 1920x1080, 64 spp as 64 passes x 1 ray/pixel, 4 bounces, one MI355X.
 
-A "step" = one full render of that frame (64 passes looped in one k_render launch, scene and
+A "step" = one full render of that frame (64 passes looped in one k_trace launch, scene and
 accumulator resident in HBM).  ray = one closest-hit query (calculateRayCollision,
 shaders/raytracer.fs.glsl:518-641 of the reference), counted exactly in-kernel by a
 separate counting launch of the same deterministic work.
@@ -41,6 +41,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-passes", type=int, default=3)
+    ap.add_argument("--strict", action="store_true", help="visit exactly the reference's box set (no distance culling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -75,6 +76,7 @@ def main() -> None:
     ctx.load_scene(scene)
     ctx.load_camera(scene.cam)
     ctx.resize(WIDTH, HEIGHT)
+    ctx.set_cull(not args.strict)          # conservative distance culling: same image bit for bit (tests), fewer box tests
     accum = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)     # kernels, events and the all-reduce share one stream
@@ -165,6 +167,7 @@ def main() -> None:
             "config": {
                 "workload": f"configs[1]: Suzanne {WIDTH}x{HEIGHT}, {PASSES} spp ({PASSES} passes x {RPP} ray/px), "
                             f"{BOUNCES} bounces, per GPU",
+                "traversal": "strict (reference box set)" if args.strict else "distance-culled (bit-identical image)",
                 "parallelism": "1 GPU, running mean" if world == 1 else
                                f"spp-sharded x{world} (pass stride {world}) + RCCL all-reduce of the {WIDTH*HEIGHT*12/1e6:.1f} MB sum",
                 "rays_per_step": int(rays_step),
@@ -173,8 +176,9 @@ def main() -> None:
                 "hits_per_ray": round(hit_step / rays_step, 3),
             },
             "roofline": {
-                "bound": "valu",
-                "kernel": "k_render<false>",
+                "bound": "mfma",
+                "engine": "f32 VALU (no GEMM shape on this path; the f32 vector-FMA peak equals the dense f32 MFMA peak)",
+                "kernel": "k_trace<STATS=false,CULL=%s,FIRST_HIT=false>" % ("false" if args.strict else "true"),
                 "achieved": round(achieved_tflops, 3),
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",

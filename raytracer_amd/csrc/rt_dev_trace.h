@@ -152,7 +152,14 @@ __device__ __forceinline__ v3 view_point_of(const DevCamera& cam, int px, int py
     return V3(r[0], r[1], r[2]);
 }
 
-enum { M_NODE = 0, M_TRI = 1, M_PATH = 2, M_DONE = 3 };
+enum { M_TRAV = 0, M_PATH = 2, M_DONE = 3 };
+
+// deferred leaves a lane can hold (the leaf queue); a lane joins a node step only while two
+// slots are free, because one node step can find two leaves
+#ifndef RT_LQ
+#define RT_LQ 2
+#endif
+#define RT_TFB_BIT 0x40000000      // tri_geo[3].w = mesh index | RT_TFB_BIT if the mesh is transparentFromBehind
 
 struct TraceArgs {
     DevScene scene;
@@ -172,14 +179,17 @@ __device__ __forceinline__ const MatDev* material_of(const DevScene& S, int idx)
     return idx < 256 ? &S.mats[idx] : &S.spheres[idx - 256].material;
 }
 
-// Traversal registers of one lane.
+// Traversal registers of one lane.  A lane holds node work (cur / node stack / mesh roots not
+// yet visited) and leaf work (the triangle in progress / the leaf queue) at the same time, so
+// it can take part in whichever kind of step the wave votes for.
 struct Trav {
-    int cur;          // reference being visited: interior >= 0, leaf < 0, RT_NONE = nothing
-    int sp;           // stack entries
-    int k;            // slot being tested while mode == M_TRI
+    int cur;          // interior record to test next (>= 0), or RT_NONE
+    int sp;           // node stack entries
+    int lq;           // leaf queue entries
+    int k;            // triangle slot in progress, or -1
     int chunk;        // group of 32 meshes whose roots are in `mask`
     uint32_t mask;    // roots of that group still to visit
-    bool hb;          // hitBehind for the mesh being walked
+    bool node_live;   // node work may remain (cleared when the last root group is exhausted)
     float best_t;
     int best_rank;
 };
@@ -206,55 +216,21 @@ __device__ __forceinline__ uint32_t root_mask(const DevScene& S, const float4* s
     return mask;
 }
 
-// The current subtree is exhausted: ONE action, no loops (divergent loops cost a chain of scalar
-// mask instructions per trip, and the scalar unit is shared by the CU's four SIMDs): pop one
-// deferred child, else take the next mesh root, else finish the query (mode = M_PATH).  When the
-// action yields nothing to visit (popped child now beyond the best hit, or a new group of roots
-// was only just tested) the lane stays in M_NODE with cur = RT_NONE and comes back here.
-template <bool STATS, bool CULL>
-__device__ __forceinline__ void next_work(const DevScene& S, const float4* s_roots, int* s_stack, unsigned short* s_stack_t,
-                                          v3 org, v3 inv, int prev_mesh, bool in_solid, Trav& tv, int& mode, Counters& cnt) {
-    int cur = RT_NONE;
-    if (tv.sp > 0) {                                               // deferred far child
-        tv.sp--;
-        cur = s_stack[tv.sp * RT_BLOCK];
-        if (CULL && unpack_dist(s_stack_t[tv.sp * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS) cur = RT_NONE;
-    } else if (tv.mask) {                                          // next mesh root
-        const int b = __builtin_ctz(tv.mask);
-        tv.mask &= tv.mask - 1;
-        const int j = tv.chunk * 32 + b;
-        cur = __float_as_int(s_roots[2 * j].w);
-        // hitBehind for triangles of mesh j (:605-615; in a solid: same mesh only [9.6])
-        tv.hb = in_solid ? (prev_mesh == j) : (__float_as_int(s_roots[2 * j + 1].w) == 0);
-    } else if ((tv.chunk + 1) * 32 >= S.n_meshes) {
-        tv.cur = RT_NONE;
-        mode = M_PATH;
-        return;
-    } else {                                                       // more than 32 meshes: next group of roots
-        tv.chunk++;
-        tv.mask = root_mask<STATS, CULL>(S, s_roots, tv.chunk, org, inv, tv.best_t, cnt);
-    }
-    tv.cur = cur;
-    const bool leaf = cur < 0 && cur != RT_NONE;
-    mode = leaf ? M_TRI : M_NODE;
-    tv.k = leaf ? ~cur : tv.k;
-}
-
 template <bool STATS, bool CULL, bool FIRST_HIT>
 __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) {
     const DevScene& S = a.scene;
-    // ---- LDS: mesh root table (2 float4 per mesh; hi.w = transparentFromBehind), then the stacks
+    // ---- LDS: mesh root table (2 float4 per mesh), then the per-lane columns
     float4* s_roots = s_mem;
     const int n_root4 = 2 * S.n_meshes;
-    for (int i = threadIdx.x; i < n_root4; i += RT_BLOCK) {
-        float4 r = S.roots[i];
-        if (i & 1) r.w = __int_as_float(S.mats[i >> 1].transparentFromBehind);
-        s_roots[i] = r;
-    }
-    // per-lane stack column: entry e at s_stack[e * RT_BLOCK]; CULL builds keep the entry
-    // distance of each deferred child in a second plane so that it can be re-culled at pop
+    for (int i = threadIdx.x; i < n_root4; i += RT_BLOCK) s_roots[i] = S.roots[i];
+    // per-lane column: node stack entries [0, stack_depth), leaf queue [stack_depth, stack_depth + RT_LQ);
+    // entry e at s_stack[e * RT_BLOCK].  CULL builds keep the entry distance of each deferred
+    // child in a second plane so that it can be re-culled when it is taken up.
+    const int n_ent = S.stack_depth + RT_LQ;
     int* s_stack = (int*)(s_mem + n_root4) + threadIdx.x;
-    unsigned short* s_stack_t = (unsigned short*)((int*)(s_mem + n_root4) + (size_t)S.stack_depth * RT_BLOCK) + threadIdx.x;
+    unsigned short* s_stack_t = (unsigned short*)((int*)(s_mem + n_root4) + (size_t)n_ent * RT_BLOCK) + threadIdx.x;
+    int* s_leaf = s_stack + (size_t)S.stack_depth * RT_BLOCK;
+    unsigned short* s_leaf_t = s_stack_t + (size_t)S.stack_depth * RT_BLOCK;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -280,79 +256,125 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     float ior = 1.0f;
     bool in_solid = false;
     Trav tv;
-    tv.cur = RT_NONE; tv.sp = 0; tv.k = 0; tv.chunk = 0; tv.mask = 0; tv.hb = false;
+    tv.cur = RT_NONE; tv.sp = 0; tv.lq = 0; tv.k = -1; tv.chunk = 0; tv.mask = 0; tv.node_live = false;
     tv.best_t = 1e20f; tv.best_rank = RT_MISS_RANK;
 
     while (true) {
-        // =============== traversal phase: NODE / TRI bursts chosen by vote ===============
+        // =============== traversal phase: node steps / triangle steps chosen by vote ===============
         while (true) {
-            const int cN = __popcll(__ballot(mode == M_NODE)), cT = __popcll(__ballot(mode == M_TRI));
-            if (cN + cT == 0) break;
-            if (cN + cT < a.refill_below && __popcll(__ballot(mode == M_PATH)) > 0) break;
-            if (STATS) { if (cN >= cT) { sch.node_steps++; sch.node_lanes += cN; } else { sch.tri_steps++; sch.tri_lanes += cT; } }
-            if (cN >= cT) {
-                if (mode == M_NODE && tv.cur == RT_NONE) {         // nothing in hand: fetch the next piece of work
-                    next_work<STATS, CULL>(S, s_roots, s_stack, s_stack_t, org, inv, prev_mat < 256 ? prev_mat : -1,
-                                           in_solid, tv, mode, cnt);
-                } else if (mode == M_NODE) {                       // :562-584, both children of `cur`
-                    const float4* n = S.nodes + 4 * (size_t)tv.cur;
-                    const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-                    const int ref1 = __float_as_int(n0.w), ref2 = __float_as_int(n1.w);
-                    float t1a, t1b, t2a, t2b;
-                    bool h1, h2;
-                    if (__ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0) {
-                        h1 = box_test_finite(org, inv, n0, n1, t1a, t1b);
-                        h2 = box_test_finite(org, inv, n2, n3, t2a, t2b);
-                    } else {                                       // a lane has an exactly zero direction component
-                        h1 = box_test(org, inv, n0, n1, t1a, t1b);
-                        h2 = box_test(org, inv, n2, n3, t2a, t2b);
+            const bool has_leaf = tv.k >= 0 || tv.lq > 0;
+            const bool can_node = tv.node_live && tv.lq <= RT_LQ - 2;
+            if (mode == M_TRAV && !has_leaf && !tv.node_live) mode = M_PATH;   // the query is finished
+            const uint64_t bN = __ballot(can_node), bT = __ballot(has_leaf);
+            const int cN = __popcll(bN), cT = __popcll(bT), cAny = __popcll(bN | bT);
+            if (cAny == 0) break;
+            if (cAny < a.refill_below && __ballot(mode == M_PATH) != 0) break;
+            if (STATS) { if (cN > cT) { sch.node_steps++; sch.node_lanes += cN; } else { sch.tri_steps++; sch.tri_lanes += cT; } }
+            if (cN > cT) {
+                if (can_node) {
+                    if (tv.cur == RT_NONE) {
+                        // ---- take up node work: a deferred far child, else the next mesh root ----
+                        if (tv.sp > 0) {
+                            tv.sp--;
+                            int c = s_stack[tv.sp * RT_BLOCK];
+                            if (CULL && unpack_dist(s_stack_t[tv.sp * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS)
+                                c = RT_NONE;
+                            tv.cur = c;
+                        } else if (tv.mask) {
+                            const int b = __builtin_ctz(tv.mask);
+                            tv.mask &= tv.mask - 1;
+                            const int ref = __float_as_int(s_roots[2 * (tv.chunk * 32 + b)].w);
+                            if (ref >= 0) tv.cur = ref;
+                            else {                                  // the mesh's root node is a leaf (:586)
+                                s_leaf[tv.lq * RT_BLOCK] = ref;
+                                if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = 0;   // distance 0: never culled
+                                tv.lq++;
+                            }
+                        } else if ((tv.chunk + 1) * 32 >= S.n_meshes) {
+                            tv.node_live = false;
+                        } else {                                    // more than 32 meshes: next group of roots
+                            tv.chunk++;
+                            tv.mask = root_mask<STATS, CULL>(S, s_roots, tv.chunk, org, inv, tv.best_t, cnt);
+                        }
                     }
-                    h1 = h1 && ref1 != RT_NONE && !culled<CULL>(t1a, t1b, tv.best_t);
-                    h2 = h2 && ref2 != RT_NONE && !culled<CULL>(t2a, t2b, tv.best_t);
-                    if (STATS) cnt.box += (ref1 != RT_NONE) + (ref2 != RT_NONE);
-                    if (h1 && h2) {                                // nearer child first
+                    if (tv.cur != RT_NONE) {                        // :562-584, both children of `cur`
+                        const float4* n = S.nodes + 4 * (size_t)tv.cur;
+                        const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                        const int ref1 = __float_as_int(n0.w), ref2 = __float_as_int(n1.w);
+                        float t1a, t1b, t2a, t2b;
+                        bool h1, h2;
+                        if (__ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0) {
+                            h1 = box_test_finite(org, inv, n0, n1, t1a, t1b);
+                            h2 = box_test_finite(org, inv, n2, n3, t2a, t2b);
+                        } else {                                    // a lane has an exactly zero direction component
+                            h1 = box_test(org, inv, n0, n1, t1a, t1b);
+                            h2 = box_test(org, inv, n2, n3, t2a, t2b);
+                        }
+                        h1 = h1 && ref1 != RT_NONE && !culled<CULL>(t1a, t1b, tv.best_t);
+                        h2 = h2 && ref2 != RT_NONE && !culled<CULL>(t2a, t2b, tv.best_t);
+                        if (STATS) cnt.box += (ref1 != RT_NONE) + (ref2 != RT_NONE);
+                        // order the children: far one first, so that the near one is taken up first
                         const bool second_near = t2a < t1a;
-                        s_stack[tv.sp * RT_BLOCK] = second_near ? ref1 : ref2;
-                        if (CULL) s_stack_t[tv.sp * RT_BLOCK] = pack_dist(second_near ? t1a : t2a);
-                        tv.sp++;
-                        tv.cur = second_near ? ref2 : ref1;
-                    } else {
-                        tv.cur = h1 ? ref1 : (h2 ? ref2 : RT_NONE);
+                        const int rn = second_near ? ref2 : ref1, rf = second_near ? ref1 : ref2;
+                        const float tn = second_near ? t2a : t1a, tf = second_near ? t1a : t2a;
+                        const bool hn = second_near ? h2 : h1, hf = second_near ? h1 : h2;
+                        if (hf && rf < 0) {
+                            s_leaf[tv.lq * RT_BLOCK] = rf;
+                            if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tf);
+                            tv.lq++;
+                        }
+                        if (hn && rn < 0) {
+                            s_leaf[tv.lq * RT_BLOCK] = rn;
+                            if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tn);
+                            tv.lq++;
+                        }
+                        const bool in_n = hn && rn >= 0, in_f = hf && rf >= 0;
+                        if (in_n && in_f) {
+                            s_stack[tv.sp * RT_BLOCK] = rf;
+                            if (CULL) s_stack_t[tv.sp * RT_BLOCK] = pack_dist(tf);
+                            tv.sp++;
+                        }
+                        tv.cur = in_n ? rn : (in_f ? rf : RT_NONE);
                     }
-                    if (tv.cur == RT_NONE)
-                        next_work<STATS, CULL>(S, s_roots, s_stack, s_stack_t, org, inv, prev_mat < 256 ? prev_mat : -1,
-                                               in_solid, tv, mode, cnt);
-                    else if (tv.cur < 0) { mode = M_TRI; tv.k = ~tv.cur; }
                 }
             } else {
-                if (mode == M_TRI) {                               // one triangle of the leaf (:593-630)
-                    const float4* g = S.tri_geo + 4 * (size_t)tv.k;
-                    const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-                    // all rejects are folded into one predicate and the three edge tests run together:
-                    // one divergent region instead of five nested ones (scalar-unit pressure)
-                    const bool tested = __float_as_int(g3.z) != prev_id;
-                    if (STATS) cnt.tri += tested;
-                    const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
-                    const v3 N = V3(g0.w, g1.w, g2.w);
-                    const float nd = dot3(N, dir);
-                    const float t = -(dot3(N, org) + g3.x) / nd;
-                    bool ok = tested && !(__builtin_fabsf(nd) < 1e-6f) && !(nd > 0.0f && !tv.hb);
-                    ok = ok && !(t < 1e-6f);                        // covers the reference's `t < 0` reject too
-                    // closer than (or tied with a later-ranked) current best; NaN t never wins
-                    ok = ok && (t < tv.best_t || (t == tv.best_t && tv.k < tv.best_rank));
-                    if (ok) {
-                        const v3 P = madd3(org, t, dir);
-                        const float e0 = dot3(N, cross3(B - A, P - A));
-                        const float e1 = dot3(N, cross3(C - B, P - B));
-                        const float e2 = dot3(N, cross3(A - C, P - C));
-                        const bool inside = !(e0 < 0.0f) && !(e1 < 0.0f) && !(e2 < 0.0f);
-                        tv.best_t = inside ? t : tv.best_t;
-                        tv.best_rank = inside ? tv.k : tv.best_rank;
+                if (has_leaf) {
+                    if (tv.k < 0) {                                 // take up the most recently found leaf
+                        tv.lq--;
+                        const int ref = s_leaf[tv.lq * RT_BLOCK];
+                        tv.k = ~ref;
+                        if (CULL && unpack_dist(s_leaf_t[tv.lq * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS)
+                            tv.k = -1;
                     }
-                    if (__float_as_int(g3.y) > 0) tv.k++;
-                    else
-                        next_work<STATS, CULL>(S, s_roots, s_stack, s_stack_t, org, inv, prev_mat < 256 ? prev_mat : -1,
-                                               in_solid, tv, mode, cnt);
+                    if (tv.k >= 0) {                                // one triangle of the leaf (:593-630)
+                        const float4* g = S.tri_geo + 4 * (size_t)tv.k;
+                        const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+                        // all rejects are folded into one predicate and the three edge tests run together:
+                        // one divergent region instead of five nested ones (scalar-unit pressure)
+                        const bool tested = __float_as_int(g3.z) != prev_id;
+                        if (STATS) cnt.tri += tested;
+                        // hitBehind for this triangle's mesh (:605-615; in a solid: same mesh only [9.6])
+                        const int mw = __float_as_int(g3.w);
+                        const bool hb = in_solid ? ((mw & ~RT_TFB_BIT) == prev_mat) : ((mw & RT_TFB_BIT) == 0);
+                        const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
+                        const v3 N = V3(g0.w, g1.w, g2.w);
+                        const float nd = dot3(N, dir);
+                        const float t = -(dot3(N, org) + g3.x) / nd;
+                        bool ok = tested && !(__builtin_fabsf(nd) < 1e-6f) && !(nd > 0.0f && !hb);
+                        ok = ok && !(t < 1e-6f);                        // covers the reference's `t < 0` reject too
+                        // closer than (or tied with a later-ranked) current best; NaN t never wins
+                        ok = ok && (t < tv.best_t || (t == tv.best_t && tv.k < tv.best_rank));
+                        if (ok) {
+                            const v3 P = madd3(org, t, dir);
+                            const float e0 = dot3(N, cross3(B - A, P - A));
+                            const float e1 = dot3(N, cross3(C - B, P - B));
+                            const float e2 = dot3(N, cross3(A - C, P - C));
+                            const bool inside = !(e0 < 0.0f) && !(e1 < 0.0f) && !(e2 < 0.0f);
+                            tv.best_t = inside ? t : tv.best_t;
+                            tv.best_rank = inside ? tv.k : tv.best_rank;
+                        }
+                        tv.k = __float_as_int(g3.y) > 0 ? tv.k + 1 : -1;
+                    }
                 }
             }
         }
@@ -535,11 +557,13 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     }
                 }
                 tv.sp = 0;
+                tv.lq = 0;
+                tv.k = -1;
                 tv.cur = RT_NONE;
                 tv.chunk = 0;
                 tv.mask = root_mask<STATS, CULL>(S, s_roots, 0, org, inv, tv.best_t, cnt);
-                next_work<STATS, CULL>(S, s_roots, s_stack, s_stack_t, org, inv, prev_mat < 256 ? prev_mat : -1, in_solid,
-                                       tv, mode, cnt);
+                tv.node_live = true;
+                mode = M_TRAV;
             }
         }
     }

@@ -35,6 +35,7 @@ struct PoseArgs {
     const int* slot_id;      // triId of each slot
     const float* xf;         // 16 floats per mesh, row-major, translation in row 3
     const unsigned char* dirty;  // per mesh: 1 = re-pose (0 = leave), 2 = copy rest (no transform yet)
+    const MatDev* mats;      // per mesh (transparentFromBehind goes into the triangle's flag word)
     float4* geo;
     float4* nrm;
     int n_slots;
@@ -71,11 +72,20 @@ __global__ __launch_bounds__(256) void k_pose(PoseArgs a) {
     g[0] = make_float4(A.x, A.y, A.z, N.x);
     g[1] = make_float4(B.x, B.y, B.z, N.y);
     g[2] = make_float4(C.x, C.y, C.z, N.z);
-    g[3] = make_float4(d, __int_as_float(a.slot_rem[k]), __int_as_float(a.slot_id[k]), 0.0f);
+    const int flags = mesh | (a.mats[mesh].transparentFromBehind ? RT_TFB_BIT : 0);
+    g[3] = make_float4(d, __int_as_float(a.slot_rem[k]), __int_as_float(a.slot_id[k]), __int_as_float(flags));
     float4* o = a.nrm + 3 * (size_t)k;
     o[0] = make_float4(n[0][0], n[0][1], n[0][2], __int_as_float(mesh));
     o[1] = make_float4(n[1][0], n[1][1], n[1][2], 0.0f);
     o[2] = make_float4(n[2][0], n[2][1], n[2][2], 0.0f);
+}
+
+// materials changed: refresh the flag word of every slot (mesh index | transparentFromBehind)
+__global__ __launch_bounds__(256) void k_tri_flags(const int* slot_mesh, const MatDev* mats, float4* geo, int n_slots) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_slots) return;
+    const int mesh = slot_mesh[k];
+    geo[4 * (size_t)k + 3].w = __int_as_float(mesh | (mats[mesh].transparentFromBehind ? RT_TFB_BIT : 0));
 }
 
 // visited-node table: c1/c2 = child visit indices (-1 none); leaves: [start, start+count) slots
@@ -215,8 +225,9 @@ struct rt_ctx {
     int n_tris = 0, n_slots = 0, n_meshes = 0, n_nodes = 0, n_visit = 0, n_rec = 0, n_spheres = 0;
     int stack_depth = 1;
     bool have_scene = false, have_cam = false, prep_pending = false;
+    bool flags_pending = false;           // materials changed since the triangle flag words were written
     bool cull = false;                    // conservative distance culling (rt_set_cull)
-    int refill_below = 40;                // lanes still traversing below which a wave shades/refills
+    int refill_below = 0;                 // lanes still traversing below which a wave shades/refills; 0 = measured default
     // camera / image
     DevCamera cam{};
     DevBuf<float> accum_own;
@@ -284,9 +295,12 @@ int run_prep(rt_ctx* c) {
     HIPCK(c, hipMemcpyAsync(c->dirty.p, c->h_dirty.data(), c->h_dirty.size(), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));   // pageable sources: h_dirty is cleared below
     if (c->n_slots) {
-        PoseArgs pa{c->rest.p, c->slot_mesh.p, c->slot_rem.p, c->slot_id.p, c->xf.p, c->dirty.p, c->geo.p, c->nrm.p, c->n_slots};
+        PoseArgs pa{c->rest.p, c->slot_mesh.p, c->slot_rem.p, c->slot_id.p, c->xf.p, c->dirty.p, c->mats.p, c->geo.p, c->nrm.p, c->n_slots};
         hipLaunchKernelGGL(k_pose, dim3(blocks_for(c->n_slots)), dim3(256), 0, c->stream, pa);
     }
+    if (c->flags_pending && c->n_slots)
+        hipLaunchKernelGGL(k_tri_flags, dim3(blocks_for(c->n_slots)), dim3(256), 0, c->stream, c->slot_mesh.p, c->mats.p, c->geo.p, c->n_slots);
+    c->flags_pending = false;
     for (int l = (int)c->level_off.size() - 2; l >= 0; l--) {
         int n = c->level_off[l + 1] - c->level_off[l];
         if (n <= 0) continue;
@@ -319,14 +333,14 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.ids = nullptr;
     a.ts = nullptr;
     a.counters = c->counters.p;
-    a.refill_below = c->refill_below;
+    a.refill_below = c->refill_below > 0 ? c->refill_below : (c->cull ? 16 : 32);   // best measured, DESIGN.md 5
 }
 
 template <bool STATS, bool CULL, bool FIRST>
 void launch_one(const rt_ctx* c, const TraceArgs& a) {
     const dim3 grid((c->cam.width + 15) / 16, (c->cam.height + 15) / 16), block(RT_BLOCK);
     // dynamic LDS: root table + per-lane stack (+ the entry-distance plane when culling)
-    const size_t lds = (size_t)2 * c->n_meshes * sizeof(float4) + (size_t)c->stack_depth * RT_BLOCK * (CULL ? 6 : 4);
+    const size_t lds = (size_t)2 * c->n_meshes * sizeof(float4) + (size_t)(c->stack_depth + RT_LQ) * RT_BLOCK * (CULL ? 6 : 4);
     hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST>), grid, block, lds, c->stream, a);
 }
 
@@ -571,6 +585,8 @@ int rt_set_materials(rt_ctx* c, const void* meshes128, int n_meshes, const void*
     if (n_meshes) HIPCK(c, hipMemcpyAsync(c->mats.p, mats.data(), (size_t)n_meshes * 80, hipMemcpyHostToDevice, c->stream));
     if (atmosphere80) std::memcpy(&c->atmo, atmosphere80, 80);
     HIPCK(c, hipStreamSynchronize(c->stream));
+    c->flags_pending = true;     // transparentFromBehind lives in the triangles' flag words
+    c->prep_pending = true;
     return RT_OK;
 }
 

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc CSV output for the k_render dispatches: tools/pmc_summary.py <dir>"""
+"""Summarise rocprofv3 --pmc CSV output for the k_trace dispatches: tools/pmc_summary.py <dir>"""
 import csv, glob, sys, collections, json
 d = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        kn = "k_trace" if ("k_trace" in k or "k_render" in k) else None
+        kn = "k_trace" if ("k_trace" in k or "k_trace" in k) else None
         if kn: agg[kn][r["Counter_Name"]] += float(r["Counter_Value"])
 for kn, c in agg.items():
     print(kn)

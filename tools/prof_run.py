@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One k_render launch of bench.py's workload (optionally fewer passes) for rocprofv3 runs.
+"""One k_trace launch of bench.py's workload (optionally fewer passes) for rocprofv3 runs.
 usage: python tools/prof_run.py [passes] [width height] [bounces]"""
 import sys
 from pathlib import Path
