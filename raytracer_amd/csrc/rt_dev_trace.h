@@ -169,6 +169,9 @@ struct TraceArgs {
     int32_t* ids;                 // W*H   (first hit)
     float* ts;                    // W*H   (first hit)
     unsigned long long* counters; // 4
+    float* totals;                // n_passes x W*H x 3: per-(pass, pixel) radiance, folded by k_accumulate
+    unsigned int* work_counter;   // next chunk to hand out (zeroed before the launch)
+    uint32_t n_chunks, n_bx, n_by;   // chunks = n_passes x n_by x n_bx blocks of 16x16 pixels
     uint32_t first_pass, n_passes, pass_stride;
     int rays_per_pixel, max_bounces, sum_mode;
     int refill_below;             // traversal yields to the path block when fewer lanes than this traverse
@@ -233,21 +236,27 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     unsigned short* s_leaf_t = s_stack_t + (size_t)S.stack_depth * RT_BLOCK;
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const bool live = px < a.cam.width && py < a.cam.height;
+    const int lane = threadIdx.x & 63;
     Counters cnt = {0, 0, 0, 0};
     SchedStats sch = {0, 0, 0, 0, 0, 0};
 
+    // ---- wave-uniform work cursor ---------------------------------------------------------
+    // Work is handed out in chunks of 256 samples = one pass over one 16x16 pixel block, taken
+    // from a launch-wide counter by whichever wave runs dry; a lane whose sample is finished
+    // takes the next one of its wave's chunk, so no lane waits for a slower neighbour and the
+    // launch ends within one chunk's time on every SIMD.
+    uint32_t w_off = 256u;     // next sample of the wave's chunk (256 = used up)
+    uint32_t w_pass = 0;
+    int w_x0 = 0, w_y0 = 0;
+    bool w_dry = false;        // the launch's counter is exhausted
+    const size_t n_px = (size_t)a.cam.width * a.cam.height;
+
     // ---- per-lane state -----------------------------------------------------------------
-    int mode = live ? M_PATH : M_DONE;
-    const v3 view_point = view_point_of(a.cam, px, py);
-    const size_t pix = (size_t)py * a.cam.width + px;
-    v3 col = V3(0.f, 0.f, 0.f), total = V3(0.f, 0.f, 0.f);
-    if (live && !FIRST_HIT) { const float* acc = a.accum + pix * 3; col = V3(acc[0], acc[1], acc[2]); }
-    uint32_t p = 0;            // passes finished
-    int s = 0;                 // samples of the current pass started
+    int mode = M_PATH;
+    bool have = false;         // holds a sample (pixel pxy of pass pass_no)
+    uint32_t pxy = 0, pass_no = 0;
+    v3 total = V3(0.f, 0.f, 0.f);
+    int s = 0;                 // paths of the current sample started
     uint32_t rng = 0;
     bool fresh = true;         // no path in flight: the path block generates a camera sample
     v3 org = V3(0.f, 0.f, 0.f), dir = V3(0.f, 0.f, 1.f), inv = V3(0.f, 0.f, 0.f);
@@ -382,8 +391,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
 
         // =============== path phase: shade the finished query, start the next one ===============
         if (STATS) { sch.path_steps++; sch.path_lanes += __popcll(__ballot(mode == M_PATH)); }
+        bool need = false, start = false;
         if (mode == M_PATH) {
-            bool start = false;
             if (!fresh) {
                 if (FIRST_HIT) {
                     int id = -1;
@@ -391,9 +400,12 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         if (tv.best_rank < 0) id = -2 - (tv.best_rank - RT_SPHERE_RANK);
                         else id = __float_as_int(S.tri_geo[4 * (size_t)tv.best_rank + 3].z);
                     }
+                    const size_t pix = (size_t)(pxy >> 16) * a.cam.width + (pxy & 0xffffu);
                     a.ids[pix] = id;
                     a.ts[pix] = tv.best_t;
-                    mode = M_DONE;
+                    have = false;
+                    fresh = true;
+                    s = 0;
                 } else if (tv.best_rank == RT_MISS_RANK) {         // miss: environment light is vec3(0) (:279-282)
                     fresh = true;
                 } else {
@@ -500,24 +512,48 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 }
                 if (fresh && !FIRST_HIT) total = total + inc;      // the path is over (:989)
             }
-            if (fresh && mode != M_DONE) {
-                if (!FIRST_HIT && s == a.rays_per_pixel) {         // a pass is complete (:1008-1021)
-                    const float rpp = (float)a.rays_per_pixel;
-                    total = V3(total.x / rpp, total.y / rpp, total.z / rpp);
-                    if (a.sum_mode) col = col + total;
-                    else {
-                        const float w = 1.0f / (float)(a.first_pass + p * a.pass_stride), om = 1.0f - w;
-                        col = V3(col.x * om + total.x * w, col.y * om + total.y * w, col.z * om + total.z * w);
-                    }
-                    total = V3(0.f, 0.f, 0.f);
-                    s = 0;
-                    p++;
-                }
-                if (p == a.n_passes) {
-                    if (!FIRST_HIT) { float* acc = a.accum + pix * 3; acc[0] = col.x; acc[1] = col.y; acc[2] = col.z; }
-                    mode = M_DONE;
-                } else {
-                    if (s == 0) rng = (uint32_t)pix + (a.first_pass + p * a.pass_stride) * 747796405u;   // :956-957
+            if (!FIRST_HIT && fresh && have && s == a.rays_per_pixel) {   // the sample is complete (:1008-1010)
+                const float rpp = (float)a.rays_per_pixel;
+                float* o = a.totals + ((size_t)pass_no * n_px + (size_t)(pxy >> 16) * a.cam.width + (pxy & 0xffffu)) * 3;
+                o[0] = total.x / rpp; o[1] = total.y / rpp; o[2] = total.z / rpp;
+                total = V3(0.f, 0.f, 0.f);
+                s = 0;
+                have = false;
+            }
+            need = fresh && !have;
+        }
+        // ---- hand out samples: wave-uniform code, reached by every lane of the wave ----
+        for (uint64_t nm = __ballot(need); nm != 0; nm = __ballot(need)) {
+            if (w_off == 256u) {
+                if (w_dry) { if (need) mode = M_DONE; break; }
+                unsigned int c = 0;
+                if (lane == 0) c = atomicAdd(a.work_counter, 1u);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c >= a.n_chunks) { w_dry = true; continue; }
+                const uint32_t per_pass = a.n_bx * a.n_by;
+                w_pass = c / per_pass;
+                const uint32_t r = c - w_pass * per_pass, by = r / a.n_bx;
+                w_x0 = (int)((r - by * a.n_bx) * 16u);
+                w_y0 = (int)(by * 16u);
+                w_off = 0;
+            }
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
+            const uint32_t avail = 256u - w_off;
+            if (need && rank < avail) {
+                const uint32_t o = w_off + rank;                   // 4 tiles of 8x8 pixels
+                const int x = w_x0 + (int)(((o >> 6) & 1u) * 8u + (o & 7u));
+                const int y = w_y0 + (int)((o >> 7) * 8u + ((o >> 3) & 7u));
+                need = false;                                      // consumed, inside the image or not
+                if (x < a.cam.width && y < a.cam.height) { have = true; pxy = (uint32_t)x | ((uint32_t)y << 16); pass_no = w_pass; }
+            }
+            w_off += min((uint32_t)__popcll(nm), avail);
+        }
+        if (mode == M_PATH) {
+            if (fresh && have) {
+                {
+                    const uint32_t pix = (pxy >> 16) * (uint32_t)a.cam.width + (pxy & 0xffffu);
+                    if (s == 0) rng = pix + (a.first_pass + pass_no * a.pass_stride) * 747796405u;   // :956-957
+                    const v3 view_point = view_point_of(a.cam, (int)(pxy & 0xffffu), (int)(pxy >> 16));
                     // camera sample (:972-987); four draws: DoF x,y then AA x,y
                     const float r1 = random_value(rng), r2 = random_value(rng), r3 = random_value(rng), r4 = random_value(rng);
                     const float nearp = a.cam.view_params[2];

@@ -159,9 +159,30 @@ __global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const 
     o[12] = a.x; o[13] = a.y; o[14] = a.z; o[16] = b.x; o[17] = b.y; o[18] = b.z; o[20] = c.x; o[21] = c.y; o[22] = c.z;
 }
 
-// One lane per pixel; a wave covers an 8x8 pixel tile, a block a 16x16 tile, so the primary
-// rays of a wave are coherent.  All passes of the launch are looped in-kernel: the pixel's
-// accumulator is read once and written once per launch.  Dynamic LDS: mesh root table + stacks.
+// Folds the per-(pass, pixel) radiance of one trace launch into the accumulator, pass by pass in
+// order, with the reference's expressions (raytracer.fs.glsl:1012-1021: running mean with weight
+// 1/pass; RT_ACCUM_SUM adds instead).  Streams n_passes x 12 B per pixel once.
+__global__ __launch_bounds__(256) void k_accumulate(const float* totals, float* accum, size_t n_px, uint32_t first_pass,
+                                                    uint32_t n_passes, uint32_t pass_stride, int sum_mode) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+    float* acc = accum + i * 3;
+    v3 col = V3(acc[0], acc[1], acc[2]);
+    for (uint32_t p = 0; p < n_passes; p++) {
+        const float* t = totals + ((size_t)p * n_px + i) * 3;
+        const v3 total = V3(t[0], t[1], t[2]);
+        if (sum_mode) col = col + total;
+        else {
+            const float w = 1.0f / (float)(first_pass + p * pass_stride), om = 1.0f - w;
+            col = V3(col.x * om + total.x * w, col.y * om + total.y * w, col.z * om + total.z * w);
+        }
+    }
+    acc[0] = col.x; acc[1] = col.y; acc[2] = col.z;
+}
+
+// Persistent waves: the grid just fills the chip, and every wave takes 16x16-pixel x 1-pass chunks
+// of samples from a launch-wide counter until none are left (rt_dev_trace.h).  Dynamic LDS: mesh
+// root table + the per-lane node stack / leaf queue columns.
 #ifndef RT_WAVES
 #define RT_WAVES 5
 #endif
@@ -215,6 +236,11 @@ struct rt_ctx {
     DevBuf<MatDev> mats;
     DevBuf<SphereDev> spheres;
     DevBuf<unsigned long long> counters;
+    DevBuf<unsigned int> work_counter;
+    DevBuf<float> totals;                 // per-(pass, pixel) radiance of one trace launch (grow-only)
+    int n_cus = 0;
+    int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per k_trace variant, for the LDS size in lds_for
+    size_t lds_for[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // scene (host mirrors)
     std::vector<float> h_xf;
     std::vector<unsigned char> h_dirty;
@@ -333,28 +359,43 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.ids = nullptr;
     a.ts = nullptr;
     a.counters = c->counters.p;
+    a.totals = c->totals.p;
+    a.work_counter = c->work_counter.p;
+    a.n_bx = (uint32_t)(c->cam.width + 15) / 16;
+    a.n_by = (uint32_t)(c->cam.height + 15) / 16;
+    a.n_chunks = 0;
     a.refill_below = c->refill_below > 0 ? c->refill_below : (c->cull ? 16 : 32);   // best measured, DESIGN.md 5
 }
 
 template <bool STATS, bool CULL, bool FIRST>
-void launch_one(const rt_ctx* c, const TraceArgs& a) {
-    const dim3 grid((c->cam.width + 15) / 16, (c->cam.height + 15) / 16), block(RT_BLOCK);
-    // dynamic LDS: root table + per-lane stack (+ the entry-distance plane when culling)
+int launch_one(rt_ctx* c, const TraceArgs& a, int key) {
+    // dynamic LDS: root table + per-lane node stack and leaf queue (+ the entry-distance plane when culling)
     const size_t lds = (size_t)2 * c->n_meshes * sizeof(float4) + (size_t)(c->stack_depth + RT_LQ) * RT_BLOCK * (CULL ? 6 : 4);
-    hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST>), grid, block, lds, c->stream, a);
+    if (c->lds_for[key] != lds || c->blocks_per_cu[key] <= 0) {
+        int nb = 0;
+        HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST>, RT_BLOCK, lds));
+        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (BVH depth %d)", lds, c->stack_depth - 1);
+        c->blocks_per_cu[key] = nb;
+        c->lds_for[key] = lds;
+    }
+    // every wave takes whole chunks: no point in more waves than chunks
+    const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_chunks + 3) / 4);
+    HIPCK(c, hipMemsetAsync(c->work_counter.p, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST>), dim3(std::max(grid, 1u)), dim3(RT_BLOCK), lds, c->stream, a);
+    return RT_OK;
 }
 
-void launch_trace(const rt_ctx* c, const TraceArgs& a, bool first_hit) {
+int launch_trace(rt_ctx* c, const TraceArgs& a, bool first_hit) {
     const int key = (c->stats_on ? 4 : 0) | (c->cull ? 2 : 0) | (first_hit ? 1 : 0);
     switch (key) {
-    case 0: launch_one<false, false, false>(c, a); break;
-    case 1: launch_one<false, false, true>(c, a); break;
-    case 2: launch_one<false, true, false>(c, a); break;
-    case 3: launch_one<false, true, true>(c, a); break;
-    case 4: launch_one<true, false, false>(c, a); break;
-    case 5: launch_one<true, false, true>(c, a); break;
-    case 6: launch_one<true, true, false>(c, a); break;
-    default: launch_one<true, true, true>(c, a); break;
+    case 0: return launch_one<false, false, false>(c, a, key);
+    case 1: return launch_one<false, false, true>(c, a, key);
+    case 2: return launch_one<false, true, false>(c, a, key);
+    case 3: return launch_one<false, true, true>(c, a, key);
+    case 4: return launch_one<true, false, false>(c, a, key);
+    case 5: return launch_one<true, false, true>(c, a, key);
+    case 6: return launch_one<true, true, false>(c, a, key);
+    default: return launch_one<true, true, true>(c, a, key);
     }
 }
 
@@ -397,7 +438,11 @@ int rt_create(int device, rt_ctx** out) {
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
     c->stream = c->own_stream;
     if (const char* e = getenv("RT_REFILL_BELOW")) c->refill_below = std::max(1, std::min(64, atoi(e)));
-    if (c->counters.alloc(16) != hipSuccess || hipMemsetAsync(c->counters.p, 0, 128, c->stream) != hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
+    if (c->n_cus <= 0) c->n_cus = 256;
+    if (c->work_counter.alloc(1) != hipSuccess || c->counters.alloc(16) != hipSuccess ||
+        hipMemsetAsync(c->counters.p, 0, 128, c->stream) != hipSuccess) {
         (void)hipStreamDestroy(c->own_stream);
         delete c;
         return RT_E_DEVICE;
@@ -421,6 +466,8 @@ int rt_destroy(rt_ctx* c) {
     for (auto& ev : c->pending_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     free_scene(c);
     c->accum_own.release();
+    c->totals.release();
+    c->work_counter.release();
     c->counters.release();
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -670,7 +717,7 @@ int rt_set_camera(rt_ctx* c, const float vp[3], const float m[16], const float p
 
 int rt_resize(rt_ctx* c, int w, int h) {
     if (!c) return RT_E_ARG;
-    if (w <= 0 || h <= 0 || (int64_t)w * h > (1 << 28)) return fail(c, RT_E_ARG, "bad image size %dx%d", w, h);
+    if (w <= 0 || h <= 0 || w > 32768 || h > 32768 || (int64_t)w * h > (1 << 28)) return fail(c, RT_E_ARG, "bad image size %dx%d", w, h);
     HIPCK(c, hipSetDevice(c->device));
     HIPCK(c, hipStreamSynchronize(c->stream));
     const bool own = (c->accum == c->accum_own.p);
@@ -722,21 +769,32 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
     a.rays_per_pixel = rpp;
     a.max_bounces = max_bounces;
     a.sum_mode = (flags == RT_ACCUM_SUM);
-    // bound the length of one launch: at most ~2^27 camera samples per launch
-    const uint64_t per_pass = (uint64_t)c->cam.width * c->cam.height * (uint64_t)rpp;
-    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (1ull << 27) / std::max<uint64_t>(per_pass, 1));
-    hipEvent_t e0, e1;
-    HIPCK(c, hipEventCreate(&e0));
-    HIPCK(c, hipEventCreate(&e1));
-    HIPCK(c, hipEventRecord(e0, c->stream));
+    // one launch traces at most ~2^27 camera samples (and at most 2^27 pixel-passes: the
+    // per-(pass, pixel) radiance buffer stays below 1.6 GB); k_accumulate then folds them in order
+    const uint64_t n_px = (uint64_t)c->cam.width * c->cam.height;
+    const uint64_t per_pass = n_px * (uint64_t)rpp;
+    const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (1ull << 27) / std::max<uint64_t>(per_pass, 1));
+    const uint32_t most = std::min(chunk, n_passes);
+    if (c->totals.n < (size_t)most * n_px * 3) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (c->totals.alloc((size_t)most * n_px * 3) != hipSuccess) return fail(c, RT_E_NOMEM, "no device memory for %u passes of radiance", most);
+    }
+    a.totals = c->totals.p;
     for (uint32_t done = 0; done < n_passes; done += chunk) {
         a.first_pass = first + done * stride;
         a.n_passes = std::min(chunk, n_passes - done);
-        launch_trace(c, a, false);
+        a.n_chunks = a.n_passes * a.n_bx * a.n_by;
+        hipEvent_t e0, e1;
+        HIPCK(c, hipEventCreate(&e0));
+        HIPCK(c, hipEventCreate(&e1));
+        HIPCK(c, hipEventRecord(e0, c->stream));
+        if ((rc = launch_trace(c, a, false))) return rc;
+        HIPCK(c, hipEventRecord(e1, c->stream));
+        c->pending_events.push_back({e0, e1});
         c->st.launches++;
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, c->stream, c->totals.p, c->accum,
+                           (size_t)n_px, a.first_pass, a.n_passes, stride, a.sum_mode);
     }
-    HIPCK(c, hipEventRecord(e1, c->stream));
-    c->pending_events.push_back({e0, e1});
     HIPCK(c, hipGetLastError());
     c->n_accum += n_passes;
     c->sum_mode = (flags == RT_ACCUM_SUM);
@@ -765,11 +823,13 @@ int rt_first_hit(rt_ctx* c, uint32_t pass, int32_t* ids, float* ts) {
     a.rays_per_pixel = 1;
     a.max_bounces = 0;
     a.sum_mode = 0;
+    a.n_chunks = a.n_bx * a.n_by;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, c->stream);
-    launch_trace(c, a, true);
+    rc = launch_trace(c, a, true);
+    if (rc) { d_ids.release(); d_ts.release(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     (void)hipEventRecord(e1, c->stream);
     c->pending_events.push_back({e0, e1});
     c->st.launches++;
