@@ -2,8 +2,8 @@
 """bench.py - Mrays/s of the rendering hot path on BASELINE.json configs[1]:
 Suzanne room, 1920x1080, 64 spp as 64 passes x 1 ray/pixel, 4 bounces, one MI355X.
 
-A "step" = one full render of that frame (64 passes looped in one k_trace launch, scene and
-accumulator resident in HBM).  ray = one closest-hit query (calculateRayCollision,
+A "step" = one full render of that frame (one persistent k_trace launch over all 64 passes plus
+one k_accumulate launch; scene and accumulator resident in HBM).  ray = one closest-hit query (calculateRayCollision,
 shaders/raytracer.fs.glsl:518-641 of the reference), counted exactly in-kernel by a
 separate counting launch of the same deterministic work.
 
@@ -130,7 +130,7 @@ def main() -> None:
     # per-launch algorithmic work of THIS rank (rank 0 reports its own kernel)
     flop_launch = (FLOP_BOX * counts["box_tests"] + FLOP_TRI * counts["tri_tests"] + FLOP_HIT * counts["shaded_hits"])
     byte_launch = (BYTE_BOX * counts["box_tests"] + BYTE_TRI * counts["tri_tests"] + BYTE_HIT * counts["shaded_hits"]
-                   + 24 * WIDTH * HEIGHT)   # accumulator read + write once per launch
+                   + 12 * WIDTH * HEIGHT * PASSES)   # k_trace writes one float3 per (pixel, pass); k_accumulate folds them
     flop_launch /= max(1, launches // max(args.steps, 1))
     byte_launch /= max(1, launches // max(args.steps, 1))
     achieved_tflops = flop_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0

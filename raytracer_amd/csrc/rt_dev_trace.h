@@ -175,6 +175,7 @@ struct TraceArgs {
     uint32_t first_pass, n_passes, pass_stride;
     int rays_per_pixel, max_bounces, sum_mode;
     int refill_below;             // traversal yields to the path block when fewer lanes than this traverse
+    int node_bias;                // a node step is taken when cN + node_bias > cT
 };
 
 // material index encoding: -1 atmosphere (kernel argument), [0,256) mesh, 256+i sphere i
@@ -278,8 +279,9 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             const int cN = __popcll(bN), cT = __popcll(bT), cAny = __popcll(bN | bT);
             if (cAny == 0) break;
             if (cAny < a.refill_below && __ballot(mode == M_PATH) != 0) break;
-            if (STATS) { if (cN > cT) { sch.node_steps++; sch.node_lanes += cN; } else { sch.tri_steps++; sch.tri_lanes += cT; } }
-            if (cN > cT) {
+            const bool do_node = cT == 0 || (cN > 0 && cN + a.node_bias > cT);   // never a step without lanes
+            if (STATS) { if (do_node) { sch.node_steps++; sch.node_lanes += cN; } else { sch.tri_steps++; sch.tri_lanes += cT; } }
+            if (do_node) {
                 if (can_node) {
                     if (tv.cur == RT_NONE) {
                         // ---- take up node work: a deferred far child, else the next mesh root ----

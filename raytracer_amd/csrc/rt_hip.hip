@@ -253,6 +253,7 @@ struct rt_ctx {
     bool have_scene = false, have_cam = false, prep_pending = false;
     bool flags_pending = false;           // materials changed since the triangle flag words were written
     bool cull = false;                    // conservative distance culling (rt_set_cull)
+    int node_bias = 0;
     int refill_below = 0;                 // lanes still traversing below which a wave shades/refills; 0 = measured default
     // camera / image
     DevCamera cam{};
@@ -364,6 +365,7 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.n_bx = (uint32_t)(c->cam.width + 15) / 16;
     a.n_by = (uint32_t)(c->cam.height + 15) / 16;
     a.n_chunks = 0;
+    a.node_bias = c->node_bias;
     a.refill_below = c->refill_below > 0 ? c->refill_below : (c->cull ? 16 : 32);   // best measured, DESIGN.md 5
 }
 
@@ -437,6 +439,7 @@ int rt_create(int device, rt_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
     c->stream = c->own_stream;
+    if (const char* e = getenv("RT_NODE_BIAS")) c->node_bias = atoi(e);
     if (const char* e = getenv("RT_REFILL_BELOW")) c->refill_below = std::max(1, std::min(64, atoi(e)));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
