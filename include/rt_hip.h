@@ -102,6 +102,22 @@ int rt_update_mesh_pose(rt_ctx* ctx, int mesh, const float pos[3], const float q
 int rt_read_tris28(rt_ctx* ctx, float* out_tris28);
 int rt_read_nodes48(rt_ctx* ctx, void* out_nodes48);
 
+/* replaces: chunker.chunk_mesh_bvh + BVHParentNode split rule (scenes/chunker.py:17-25, 113-245)
+ * and the flat leaf id list of BVHGraph.register_all_and_update_node_tri_ids (:79-86) for ONE
+ * mesh, on the host, natively (the Python builder cannot do 10^6 triangles).  No context and no
+ * GPU needed.  pos9 = n_tris x 9 float32 (A, B, C of each triangle, current pose).  Node ids
+ * start at first_node_id (creation order: both children before either subtree), leaf triangle
+ * ids are first_tri_id + local index, leaf offsets start at first_leaf_offset.  Writes
+ * *n_nodes_out std140 nodes (48 B, chunker.py:247-257) and exactly n_tris leaf ids.
+ * RT_E_LIMIT if nodes_cap is too small (2*n_tris always suffices). */
+int rt_bvh_build(const float* pos9, int n_tris, int32_t first_node_id, int32_t first_tri_id,
+                 int32_t first_leaf_offset, void* nodes48_out, int nodes_cap,
+                 int32_t* leaf_tri_ids_out, int32_t* n_nodes_out);
+/* replaces: BVHGraph.update_graph_node_aabbs_for_changed_triangles (chunker.py:94-106, 197-214)
+ * on the host: boxes of every node from the current positions, bottom-up (exact: min/max). */
+int rt_bvh_refit(const float* pos9, int n_tris, int32_t first_tri_id, int32_t first_leaf_offset,
+                 void* nodes48, int n_nodes, const int32_t* leaf_tri_ids);
+
 /* replaces: the camera uniform writes of calculate_frame (application.py:1175-1180):
  * ViewParams, CamLocalToWorldMatrix (numpy row-major float32 bytes), CamGlobalPos,
  * depthOfFieldStrength, antialiasStrength */

@@ -880,3 +880,122 @@ int rto_set_threads(int n) {
     (void)n; return 1;
 #endif
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * BVH construction / refit - restatement of scripts/scenes/chunker.py of the reference
+ * (chunk_mesh_bvh :17-25; BVHParentNode.__init__/split/split_recursively :113-195: node ids in
+ * creation order, centroid = mean of the three corners frozen at construction, longest axis
+ * halved, "inside the lower half-box, inclusive" goes left, no split when one side is empty,
+ * stop at <= 5 triangles or depth 20; refit :197-214 = min/max over ALL of a node's own
+ * triangles; register_all_and_update_node_tri_ids :79-86; std140 image :247-257).
+ * Plain recursive C, every node keeps its full triangle list like the reference does.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { float lo[3], pad, hi[3]; int32_t id, c1, c2, off, cnt; } ONode48;
+typedef struct ONode { int *tris; int n, depth, left, right; float lo[3], hi[3]; } ONode;
+typedef struct { const float* pos; ONode* nodes; int n_nodes, cap; } OBuild;
+
+static void onode_box(const float* pos, const int* tris, int n, float lo[3], float hi[3]) {
+    if (n == 0) { for (int c = 0; c < 3; c++) lo[c] = hi[c] = 0.0f; return; }
+    for (int c = 0; c < 3; c++) { lo[c] = INFINITY; hi[c] = -INFINITY; }
+    for (int i = 0; i < n; i++)
+        for (int v = 0; v < 3; v++)
+            for (int c = 0; c < 3; c++) {
+                float x = pos[9 * (size_t)tris[i] + 3 * v + c];
+                lo[c] = x < lo[c] ? x : lo[c];
+                hi[c] = x > hi[c] ? x : hi[c];
+            }
+}
+static int onode_new(OBuild* b, int* tris, int n, int depth) {
+    if (b->n_nodes == b->cap) { b->cap *= 2; b->nodes = (ONode*)realloc(b->nodes, (size_t)b->cap * sizeof(ONode)); }
+    ONode* nd = &b->nodes[b->n_nodes];
+    nd->tris = tris; nd->n = n; nd->depth = depth; nd->left = nd->right = -1;
+    onode_box(b->pos, tris, n, nd->lo, nd->hi);
+    return b->n_nodes++;
+}
+static void onode_split_recursively(OBuild* b, int ni) {
+    if (b->nodes[ni].n <= 5 || b->nodes[ni].depth == 20) return;
+    ONode nd = b->nodes[ni];
+    int axis = 0;
+    for (int c = 1; c < 3; c++) if (fabsf(nd.lo[c] - nd.hi[c]) > fabsf(nd.lo[axis] - nd.hi[axis])) axis = c;
+    float half[3] = {0.0f, 0.0f, 0.0f}, lh[3];
+    half[axis] = 0.5f;
+    for (int c = 0; c < 3; c++) lh[c] = nd.hi[c] - (nd.hi[c] - nd.lo[c]) * half[c];
+    int* l = (int*)malloc((size_t)nd.n * sizeof(int));
+    int* r = (int*)malloc((size_t)nd.n * sizeof(int));
+    int nl = 0, nr = 0;
+    for (int i = 0; i < nd.n; i++) {
+        const float* p = b->pos + 9 * (size_t)nd.tris[i];
+        int in = 1;
+        for (int c = 0; c < 3; c++) {
+            float cen = ((p[c] + p[3 + c]) + p[6 + c]) / 3.0f;     /* np.mean(vertices, axis=1), float32 */
+            if (!(cen >= nd.lo[c] && cen <= lh[c])) in = 0;
+        }
+        if (in) l[nl++] = nd.tris[i]; else r[nr++] = nd.tris[i];
+    }
+    if (nl == 0 || nr == 0) { free(l); free(r); return; }
+    int li = onode_new(b, l, nl, nd.depth + 1);
+    int ri = onode_new(b, r, nr, nd.depth + 1);
+    b->nodes[ni].left = li; b->nodes[ni].right = ri;
+    onode_split_recursively(b, li);
+    onode_split_recursively(b, ri);
+}
+int rt_bvh_build(const float* pos9, int n_tris, int32_t first_node_id, int32_t first_tri_id, int32_t first_leaf_offset,
+                 void* nodes48_out, int nodes_cap, int32_t* leaf_tri_ids_out, int32_t* n_nodes_out) {
+    if (!pos9 || n_tris <= 0 || !nodes48_out || !leaf_tri_ids_out || !n_nodes_out || nodes_cap <= 0) return RT_E_ARG;
+    OBuild b = {pos9, (ONode*)malloc(64 * sizeof(ONode)), 0, 64};
+    int* all = (int*)malloc((size_t)n_tris * sizeof(int));
+    for (int i = 0; i < n_tris; i++) all[i] = i;
+    onode_split_recursively(&b, onode_new(&b, all, n_tris, 0));
+    int rc = RT_OK;
+    if (b.n_nodes > nodes_cap) rc = RT_E_LIMIT;
+    else {
+        ONode48* out = (ONode48*)nodes48_out;
+        int32_t off = first_leaf_offset;
+        size_t w = 0;
+        for (int i = 0; i < b.n_nodes; i++) {
+            ONode* nd = &b.nodes[i];
+            memset(&out[i], 0, sizeof(ONode48));
+            for (int c = 0; c < 3; c++) { out[i].lo[c] = nd->lo[c]; out[i].hi[c] = nd->hi[c]; }
+            out[i].id = first_node_id + i;
+            out[i].c1 = nd->left < 0 ? -1 : first_node_id + nd->left;
+            out[i].c2 = nd->right < 0 ? -1 : first_node_id + nd->right;
+            out[i].cnt = nd->n;
+            out[i].off = -1;
+            if (nd->left < 0 && nd->right < 0) {
+                out[i].off = off;
+                for (int k = 0; k < nd->n; k++) leaf_tri_ids_out[w++] = first_tri_id + nd->tris[k];
+                off += nd->n;
+            }
+        }
+        *n_nodes_out = b.n_nodes;
+    }
+    for (int i = 0; i < b.n_nodes; i++) free(b.nodes[i].tris);
+    free(b.nodes);
+    return rc;
+}
+/* refit as the reference does it: every node over all triangles below it (here: gathered by
+ * walking down to its leaves), not bottom-up */
+static void orefit_gather(const float* pos9, const ONode48* nodes, int32_t id0, int i, int32_t first_tri_id, int32_t leaf0,
+                          const int32_t* ids, float lo[3], float hi[3]) {
+    const ONode48* nd = &nodes[i];
+    if (nd->c1 < 0 && nd->c2 < 0) {
+        for (int k = 0; k < nd->cnt; k++) {
+            const float* p = pos9 + 9 * (size_t)(ids[nd->off - leaf0 + k] - first_tri_id);
+            for (int q = 0; q < 9; q++) { int c = q % 3; lo[c] = p[q] < lo[c] ? p[q] : lo[c]; hi[c] = p[q] > hi[c] ? p[q] : hi[c]; }
+        }
+        return;
+    }
+    if (nd->c1 >= 0) orefit_gather(pos9, nodes, id0, nd->c1 - id0, first_tri_id, leaf0, ids, lo, hi);
+    if (nd->c2 >= 0) orefit_gather(pos9, nodes, id0, nd->c2 - id0, first_tri_id, leaf0, ids, lo, hi);
+}
+int rt_bvh_refit(const float* pos9, int n_tris, int32_t first_tri_id, int32_t first_leaf_offset, void* nodes48, int n_nodes,
+                 const int32_t* leaf_tri_ids) {
+    if (!pos9 || n_tris <= 0 || !nodes48 || n_nodes <= 0 || !leaf_tri_ids) return RT_E_ARG;
+    ONode48* nodes = (ONode48*)nodes48;
+    for (int i = 0; i < n_nodes; i++) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        orefit_gather(pos9, nodes, nodes[0].id, i, first_tri_id, first_leaf_offset, leaf_tri_ids, lo, hi);
+        for (int c = 0; c < 3; c++) { nodes[i].lo[c] = lo[c]; nodes[i].hi[c] = hi[c]; }
+    }
+    return RT_OK;
+}

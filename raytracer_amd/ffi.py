@@ -53,6 +53,8 @@ _SIGNATURES = {
     "rt_update_mesh_pose": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "rt_read_tris28": (C.c_int, [_vp, _vp]),
     "rt_read_nodes48": (C.c_int, [_vp, _vp]),
+    "rt_bvh_build": (C.c_int, [_vp, C.c_int, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int, _vp, C.POINTER(C.c_int32)]),
+    "rt_bvh_refit": (C.c_int, [_vp, C.c_int, C.c_int32, C.c_int32, _vp, C.c_int, _vp]),
     "rt_set_camera": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_float]),
     "rt_resize": (C.c_int, [_vp, C.c_int, C.c_int]),
     "rt_reset_accum": (C.c_int, [_vp]),
@@ -104,6 +106,35 @@ class RtLib:
 
     def create(self, device: int = 0) -> "RtContext":
         return RtContext(self, device)
+
+    # -- host-side BVH (no context, no GPU) -------------------------------------------------
+    def bvh_build(self, pos: np.ndarray, first_node_id: int = 0, first_tri_id: int = 0, first_leaf_offset: int = 0,
+                  node_dtype=None):
+        """(nodes48, leaf_tri_ids) of one mesh, built natively with the reference's split rule.
+        pos = (n, 3, 3) float32 corner positions."""
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 9)
+        n = pos.shape[0]
+        cap = 2 * n
+        nodes = np.zeros(cap * 48, dtype=np.uint8)
+        ids = np.zeros(n, dtype=np.int32)
+        n_nodes = C.c_int32(0)
+        rc = self.dll.rt_bvh_build(_ptr(pos), n, first_node_id, first_tri_id, first_leaf_offset, _ptr(nodes), cap, _ptr(ids),
+                                   C.byref(n_nodes))
+        if rc != 0:
+            raise RtError(rc, "rt_bvh_build", "bad arguments" if rc == -1 else "node capacity")
+        nodes = nodes[: n_nodes.value * 48].copy()
+        return (nodes.view(node_dtype) if node_dtype is not None else nodes), ids
+
+    def bvh_refit(self, pos: np.ndarray, nodes: np.ndarray, leaf_ids: np.ndarray, first_tri_id: int = 0,
+                  first_leaf_offset: int = 0) -> None:
+        """Recompute the boxes of `nodes` (modified in place) from the current positions."""
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 9)
+        assert nodes.flags.c_contiguous and nodes.nbytes % 48 == 0
+        leaf_ids = np.ascontiguousarray(leaf_ids, dtype=np.int32)
+        rc = self.dll.rt_bvh_refit(_ptr(pos), pos.shape[0], first_tri_id, first_leaf_offset, _ptr(nodes), nodes.nbytes // 48,
+                                   _ptr(leaf_ids))
+        if rc != 0:
+            raise RtError(rc, "rt_bvh_refit", "inconsistent arguments")
 
 
 class RtContext:

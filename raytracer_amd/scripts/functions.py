@@ -60,7 +60,7 @@ def export_scene_buffers(scene: Scene, rest_pose: bool = False) -> dict:
     return {
         "tris28": tris,
         "meshes128": pack_records(Mesh.ALL, MESH_DTYPE),
-        "nodes48": pack_records(chunker.BVHParentNode.ALL, chunker.NODE_DTYPE),
+        "nodes48": chunker.BVHGraph.all_node_records(),
         "leaf_tri_ids": np.asarray(chunker.BVHGraph.BVH_TRI_ID_LIST_GLOBAL, dtype=np.int32),
         "spheres96": pack_records(scene.spheres, SPHERE_DTYPE),
         "atmosphere80": scene.atmosphere_material.as_record().reshape(1),

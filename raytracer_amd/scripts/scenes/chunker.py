@@ -38,12 +38,17 @@ def point_in_aabb(point, aabb) -> bool:
     return bool(np.all(point >= aabb[0]) and np.all(point <= aabb[1]))
 
 
-def chunk_mesh_bvh(mesh) -> None:
-    """Build ``mesh.bvh_graph`` (chunker.py:17-25)."""
-    graph = BVHGraph(mesh=mesh)
+def chunk_mesh_bvh(mesh, lib=None) -> None:
+    """Build ``mesh.bvh_graph`` (chunker.py:17-25).  With ``lib`` (a loaded C-ABI library,
+    ``raytracer_amd.ffi.RtLib``) the graph is built natively by ``rt_bvh_build`` - same rule,
+    same bytes (tests/test_bvh_native.py) - which is what makes 10^6-triangle meshes usable."""
     if not len(mesh.triangles):
         print("Warning, no triangles detected in mesh, returning without mesh!")
         raise Exception
+    if lib is not None:
+        mesh.bvh_graph = NativeBVHGraph(mesh, lib)
+        return
+    graph = BVHGraph(mesh=mesh)
     root = BVHParentNode(graph=graph, tris=np.arange(len(mesh.triangles), dtype=np.int64), depth=0)
     root.split_recursively(max_depth=MAX_DEPTH)
     mesh.bvh_graph = graph
@@ -52,6 +57,8 @@ def chunk_mesh_bvh(mesh) -> None:
 class BVHGraph:
     BVH_TRI_ID_LIST_GLOBAL: list[int] = []
     ALL: list["BVHGraph"] = []
+
+    N_NODES_GLOBAL = 0       # node ids are global over all graphs, in creation order
 
     def __init__(self, mesh) -> None:
         self.id = len(BVHGraph.ALL)
@@ -85,18 +92,37 @@ class BVHGraph:
     def register_all_and_update_node_tri_ids() -> None:
         """Flat leaf triangle-id list: graphs in creation order, leaves in creation order
         (chunker.py:79-86)."""
-        flat: list[int] = []
+        parts: list[np.ndarray] = []
+        at = 0
         for g in BVHGraph.ALL:
-            g.update_leaf_nodes_and_tri_ids()
-            for node in g.leaf_nodes:
-                node.tris_start_offset = len(flat)
-                flat += node.tri_ids.tolist()
-        BVHGraph.BVH_TRI_ID_LIST_GLOBAL = flat
+            at = g._register_leaves(at, parts)
+        BVHGraph.BVH_TRI_ID_LIST_GLOBAL = np.concatenate(parts).astype(np.int32) if parts else np.zeros(0, np.int32)
+
+    def _register_leaves(self, at: int, parts: list) -> int:
+        self.update_leaf_nodes_and_tri_ids()
+        for node in self.leaf_nodes:
+            node.tris_start_offset = at
+            parts.append(node.tri_ids)
+            at += node.tris_count
+        return at
+
+    def node_records(self) -> np.ndarray:
+        """std140 image of this graph's nodes, creation order."""
+        out = np.zeros(len(self._nodes), dtype=NODE_DTYPE)
+        for i, n in enumerate(self._nodes):
+            out[i] = n.as_record()
+        return out
+
+    @staticmethod
+    def all_node_records() -> np.ndarray:
+        recs = [g.node_records() for g in BVHGraph.ALL]
+        return np.concatenate(recs) if recs else np.zeros(0, dtype=NODE_DTYPE)
 
     @staticmethod
     def reset() -> None:
         BVHGraph.BVH_TRI_ID_LIST_GLOBAL = []
         BVHGraph.ALL = []
+        BVHGraph.N_NODES_GLOBAL = 0
 
     def update_graph_node_aabbs_for_changed_triangles(self, force: bool = False) -> None:
         if (not force) and (not self.is_awaiting_mesh_update):
@@ -106,12 +132,51 @@ class BVHGraph:
         self.unflag_for_mesh_update()
 
 
+class NativeBVHGraph(BVHGraph):
+    """A graph held as the arrays ``rt_bvh_build`` returns (no per-node Python objects)."""
+
+    def __init__(self, mesh, lib) -> None:
+        super().__init__(mesh)
+        self.lib = lib
+        ts = mesh.triangles
+        self.first_tri_id = int(ts.ids[0])
+        assert np.array_equal(ts.ids, np.arange(self.first_tri_id, self.first_tri_id + len(ts), dtype=ts.ids.dtype))
+        self.nodes48, self.leaf_ids = lib.bvh_build(ts.pos, BVHGraph.N_NODES_GLOBAL, self.first_tri_id, 0, NODE_DTYPE)
+        BVHGraph.N_NODES_GLOBAL += len(self.nodes48)
+        self.leaf_base = 0
+
+    @property
+    def nodes(self):
+        raise AttributeError("a native graph has no node objects; use node_records()")
+
+    @property
+    def first_node_id(self) -> int:
+        return int(self.nodes48["id"][0])
+
+    def _register_leaves(self, at: int, parts: list) -> int:
+        leaf = self.nodes48["childObjOffset"] >= 0
+        self.nodes48["childObjOffset"][leaf] += at - self.leaf_base
+        self.leaf_base = at
+        parts.append(self.leaf_ids)
+        return at + len(self.leaf_ids)
+
+    def node_records(self) -> np.ndarray:
+        return self.nodes48
+
+    def update_graph_node_aabbs_for_changed_triangles(self, force: bool = False) -> None:
+        if (not force) and (not self.is_awaiting_mesh_update):
+            return
+        self.lib.bvh_refit(self.mesh.triangles.pos, self.nodes48, self.leaf_ids, self.first_tri_id, self.leaf_base)
+        self.unflag_for_mesh_update()
+
+
 class BVHParentNode:
     ALL: list["BVHParentNode"] = []
 
     def __init__(self, graph: BVHGraph, tris: np.ndarray, depth: int) -> None:
         self.graph = graph
-        self.id = len(BVHParentNode.ALL)
+        self.id = BVHGraph.N_NODES_GLOBAL
+        BVHGraph.N_NODES_GLOBAL += 1
         BVHParentNode.ALL.append(self)
         self.depth = depth
         self.child_left: BVHParentNode | None = None

@@ -120,9 +120,13 @@ def get_frame_number(obj: Scene, i):
 
 
 # ---- scene construction ------------------------------------------------------------------------
-def build(subject_file: str = MONKEY_FILE, subject_triangles=None) -> Scene:
+def build(subject_file: str = MONKEY_FILE, subject_triangles=None, lib=None, subdivide: int = 0) -> Scene:
     """Build the 9-mesh scene.  ``subject_triangles`` = optional (pos, nrm) arrays replacing
-    the subject's OBJ (used for the subdivided-Suzanne configuration)."""
+    the subject's OBJ; ``subdivide`` = midpoint-split the subject that many times (5 = the
+    991 232-triangle configs[3]); ``lib`` = build the BVHs natively (``rt_bvh_build``)."""
+    if subdivide:
+        from .utils import read_obj, subdivide_triangles
+        subject_triangles = subdivide_triangles(*read_obj(subject_file), subdivide)
     reset_global_datas()
     mats = {
         "subject": Material(_rgba(1.0, 1.0, 1.0), Vector3((0.0, 0.0, 0.0), dtype="f4"),
@@ -169,7 +173,7 @@ def build(subject_file: str = MONKEY_FILE, subject_triangles=None) -> Scene:
         if k == 0:
             subject = mesh
         sc.meshes.append(mesh)
-        chunker.chunk_mesh_bvh(mesh)
+        chunker.chunk_mesh_bvh(mesh, lib)
     chunker.BVHGraph.register_all_and_update_node_tri_ids()
     sc.subject_mesh = subject
 

@@ -93,6 +93,33 @@ def reset_global_datas() -> None:
     chunker.BVHParentNode.reset()
 
 
+def subdivide_triangles(pos: np.ndarray, nrm: np.ndarray, levels: int):
+    """Pure 1 -> 4 midpoint split, `levels` times (BASELINE.json configs[3], SURVEY.md 8(d)
+    config 4): new corners are float32 edge midpoints (projected nowhere), their normals the
+    renormalised sum of the edge's two corner normals.  Children of a triangle stay together,
+    in the order (A,ab,ca) (ab,B,bc) (ca,bc,C) (ab,bc,ca).  Deterministic synthetic data."""
+    pos = np.asarray(pos, dtype=np.float32)
+    nrm = np.asarray(nrm, dtype=np.float32)
+
+    def mid_n(a, b):
+        v = a + b
+        ln = np.sqrt((v * v).sum(axis=-1, keepdims=True)).astype(np.float32)
+        return np.where(ln > 0, v / np.where(ln > 0, ln, 1), a).astype(np.float32)
+
+    for _ in range(levels):
+        a, b, c = pos[:, 0], pos[:, 1], pos[:, 2]
+        na, nb, nc = nrm[:, 0], nrm[:, 1], nrm[:, 2]
+        h = np.float32(0.5)
+        ab, bc, ca = (a + b) * h, (b + c) * h, (c + a) * h
+        nab, nbc, nca = mid_n(na, nb), mid_n(nb, nc), mid_n(nc, na)
+        pos = np.stack([np.stack([a, ab, ca], 1), np.stack([ab, b, bc], 1), np.stack([ca, bc, c], 1), np.stack([ab, bc, ca], 1)], 1)
+        nrm = np.stack([np.stack([na, nab, nca], 1), np.stack([nab, nb, nbc], 1), np.stack([nca, nbc, nc], 1),
+                        np.stack([nab, nbc, nca], 1)], 1)
+        pos = np.ascontiguousarray(pos.reshape(-1, 3, 3), dtype=np.float32)
+        nrm = np.ascontiguousarray(nrm.reshape(-1, 3, 3), dtype=np.float32)
+    return pos, nrm
+
+
 def smoothstep(edge0, edge1, x):
     t = np.clip((x - edge0) / (edge1 - edge0), 0.0, 1.0)
     return t * t * (3 - 2 * t)

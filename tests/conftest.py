@@ -36,6 +36,14 @@ def hip_lib():
     return RtLib()  # raises loudly if librt_hip.so is missing
 
 
+@pytest.fixture(scope="session")
+def hip_lib_cpu():
+    """The product library for its host-only entry points (rt_bvh_*): loads without a GPU."""
+    from raytracer_amd.ffi import RtLib
+
+    return RtLib()
+
+
 def build_suzanne(frame=0):
     from raytracer_amd.scripts.scenes import final_scene_numba as S
 
