@@ -152,6 +152,9 @@ __device__ __forceinline__ v3 view_point_of(const DevCamera& cam, int px, int py
     return V3(r[0], r[1], r[2]);
 }
 
+struct PathConsts { DevCamera cam; MatDev atmo; };
+#define RT_PC_F4 ((int)((sizeof(PathConsts) + 15) / 16))   // float4 slots of LDS it takes
+
 enum { M_TRAV = 0, M_PATH = 2, M_DONE = 3 };
 
 // deferred leaves a lane can hold (the leaf queue); a lane joins a node step only while two
@@ -227,12 +230,18 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     float4* s_roots = s_mem;
     const int n_root4 = 2 * S.n_meshes;
     for (int i = threadIdx.x; i < n_root4; i += RT_BLOCK) s_roots[i] = S.roots[i];
+    // camera and atmosphere constants: read from LDS where the path block needs them, instead of
+    // ~50 scalar registers held (and spilled) across the traversal loop
+    PathConsts* s_pc = (PathConsts*)(s_mem + n_root4);
+    if (threadIdx.x == 0) { s_pc->cam = a.cam; s_pc->atmo = a.atmo; }
+    const DevCamera& cam = s_pc->cam;
+    const MatDev& atmo = s_pc->atmo;
     // per-lane column: node stack entries [0, stack_depth), leaf queue [stack_depth, stack_depth + RT_LQ);
     // entry e at s_stack[e * RT_BLOCK].  CULL builds keep the entry distance of each deferred
     // child in a second plane so that it can be re-culled when it is taken up.
     const int n_ent = S.stack_depth + RT_LQ;
-    int* s_stack = (int*)(s_mem + n_root4) + threadIdx.x;
-    unsigned short* s_stack_t = (unsigned short*)((int*)(s_mem + n_root4) + (size_t)n_ent * RT_BLOCK) + threadIdx.x;
+    int* s_stack = (int*)(s_mem + n_root4 + RT_PC_F4) + threadIdx.x;
+    unsigned short* s_stack_t = (unsigned short*)((int*)(s_mem + n_root4 + RT_PC_F4) + (size_t)n_ent * RT_BLOCK) + threadIdx.x;
     int* s_leaf = s_stack + (size_t)S.stack_depth * RT_BLOCK;
     unsigned short* s_leaf_t = s_stack_t + (size_t)S.stack_depth * RT_BLOCK;
     __syncthreads();
@@ -250,13 +259,12 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     uint32_t w_pass = 0;
     int w_x0 = 0, w_y0 = 0;
     bool w_dry = false;        // the launch's counter is exhausted
-    const size_t n_px = (size_t)a.cam.width * a.cam.height;
+    const size_t n_px = (size_t)cam.width * cam.height;
 
     // ---- per-lane state -----------------------------------------------------------------
     int mode = M_PATH;
     bool have = false;         // holds a sample (pixel pxy of pass pass_no)
     uint32_t pxy = 0, pass_no = 0;
-    v3 total = V3(0.f, 0.f, 0.f);
     int s = 0;                 // paths of the current sample started
     uint32_t rng = 0;
     bool fresh = true;         // no path in flight: the path block generates a camera sample
@@ -402,7 +410,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         if (tv.best_rank < 0) id = -2 - (tv.best_rank - RT_SPHERE_RANK);
                         else id = __float_as_int(S.tri_geo[4 * (size_t)tv.best_rank + 3].z);
                     }
-                    const size_t pix = (size_t)(pxy >> 16) * a.cam.width + (pxy & 0xffffu);
+                    const size_t pix = (size_t)(pxy >> 16) * cam.width + (pxy & 0xffffu);
                     a.ids[pix] = id;
                     a.ts[pix] = tv.best_t;
                     have = false;
@@ -455,7 +463,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         inc = inc + V3(m->emissionColor[0] * es, m->emissionColor[1] * es, m->emissionColor[2] * es) * thr;
                         const float nf = backside ? -1.0f : 1.0f;
                         const v3 nrm = normal * nf;
-                        const float n2 = (in_solid && backside) ? a.atmo.ior : m->ior;
+                        const float n2 = (in_solid && backside) ? atmo.ior : m->ior;
                         const float n1 = ior;
                         v3 diffuse = normalize3((-nrm) + random_direction(rng));
                         const float costheta = clampf(dot3(normalize3(nrm), normalize3(-dir)), -1.0f, 1.0f);
@@ -471,8 +479,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             diffuse = -diffuse;
                         } else if (random_value(rng) > schlick) {
                             if (random_value(rng) < m->transmission) {   // :822-847
-                                float pc0 = a.atmo.color[0], pc1 = a.atmo.color[1], pc2 = a.atmo.color[2];
-                                float pc3 = a.atmo.color[3], ptr = a.atmo.transmission;
+                                float pc0 = atmo.color[0], pc1 = atmo.color[1], pc2 = atmo.color[2];
+                                float pc3 = atmo.color[3], ptr = atmo.transmission;
                                 if (prev_mat >= 0) {
                                     const MatDev* pm = material_of(S, prev_mat);
                                     pc0 = pm->color[0]; pc1 = pm->color[1]; pc2 = pm->color[2]; pc3 = pm->color[3];
@@ -482,7 +490,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 const float e = det_exp(-at * best_t);
                                 const v3 tc = V3(pc0, pc1, pc2) * e;
                                 thr = thr * (tc * pc3);
-                                if (backside) { in_solid = false; ior = a.atmo.ior; }
+                                if (backside) { in_solid = false; ior = atmo.ior; }
                                 else { in_solid = true; ior = m->ior; }
                             } else {
                                 diffuse = -diffuse;
@@ -512,15 +520,14 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     if (ended) fresh = true;
                     else { bounce++; start = true; }
                 }
-                if (fresh && !FIRST_HIT) total = total + inc;      // the path is over (:989)
-            }
-            if (!FIRST_HIT && fresh && have && s == a.rays_per_pixel) {   // the sample is complete (:1008-1010)
-                const float rpp = (float)a.rays_per_pixel;
-                float* o = a.totals + ((size_t)pass_no * n_px + (size_t)(pxy >> 16) * a.cam.width + (pxy & 0xffffu)) * 3;
-                o[0] = total.x / rpp; o[1] = total.y / rpp; o[2] = total.z / rpp;
-                total = V3(0.f, 0.f, 0.f);
-                s = 0;
-                have = false;
+                if (fresh && !FIRST_HIT) {                         // the path is over (:989): totalIncomingLight += inc
+                    // the sample's running sum lives in the radiance buffer (three fewer live registers);
+                    // k_accumulate divides by RAYS_PER_PIXEL (:1009)
+                    float* o = a.totals + ((size_t)pass_no * n_px + (size_t)(pxy >> 16) * cam.width + (pxy & 0xffffu)) * 3;
+                    const v3 sum = s == 1 ? V3(0.f, 0.f, 0.f) : V3(o[0], o[1], o[2]);
+                    o[0] = sum.x + inc.x; o[1] = sum.y + inc.y; o[2] = sum.z + inc.z;
+                    if (s == a.rays_per_pixel) { s = 0; have = false; }   // the sample is complete (:1008-1010)
+                }
             }
             need = fresh && !have;
         }
@@ -546,27 +553,27 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 const int x = w_x0 + (int)(((o >> 6) & 1u) * 8u + (o & 7u));
                 const int y = w_y0 + (int)((o >> 7) * 8u + ((o >> 3) & 7u));
                 need = false;                                      // consumed, inside the image or not
-                if (x < a.cam.width && y < a.cam.height) { have = true; pxy = (uint32_t)x | ((uint32_t)y << 16); pass_no = w_pass; }
+                if (x < cam.width && y < cam.height) { have = true; pxy = (uint32_t)x | ((uint32_t)y << 16); pass_no = w_pass; }
             }
             w_off += min((uint32_t)__popcll(nm), avail);
         }
         if (mode == M_PATH) {
             if (fresh && have) {
                 {
-                    const uint32_t pix = (pxy >> 16) * (uint32_t)a.cam.width + (pxy & 0xffffu);
+                    const uint32_t pix = (pxy >> 16) * (uint32_t)cam.width + (pxy & 0xffffu);
                     if (s == 0) rng = pix + (a.first_pass + pass_no * a.pass_stride) * 747796405u;   // :956-957
-                    const v3 view_point = view_point_of(a.cam, (int)(pxy & 0xffffu), (int)(pxy >> 16));
+                    const v3 view_point = view_point_of(cam, (int)(pxy & 0xffffu), (int)(pxy >> 16));
                     // camera sample (:972-987); four draws: DoF x,y then AA x,y
                     const float r1 = random_value(rng), r2 = random_value(rng), r3 = random_value(rng), r4 = random_value(rng);
-                    const float nearp = a.cam.view_params[2];
-                    const v3 dofo = V3(((r1 * 2.0f - 1.0f) * a.cam.dof) * nearp, ((r2 * 2.0f - 1.0f) * a.cam.dof) * nearp,
-                                       ((0.0f * 2.0f - 1.0f) * a.cam.dof) * nearp);
-                    const v3 aao = V3((r3 * 2.0f - 1.0f) * a.cam.aa, (r4 * 2.0f - 1.0f) * a.cam.aa, (0.0f * 2.0f - 1.0f) * a.cam.aa);
+                    const float nearp = cam.view_params[2];
+                    const v3 dofo = V3(((r1 * 2.0f - 1.0f) * cam.dof) * nearp, ((r2 * 2.0f - 1.0f) * cam.dof) * nearp,
+                                       ((0.0f * 2.0f - 1.0f) * cam.dof) * nearp);
+                    const v3 aao = V3((r3 * 2.0f - 1.0f) * cam.aa, (r4 * 2.0f - 1.0f) * cam.aa, (0.0f * 2.0f - 1.0f) * cam.aa);
                     dir = normalize3((view_point + dofo) + aao);
-                    org = V3(a.cam.cam_pos[0], a.cam.cam_pos[1], a.cam.cam_pos[2]) - dofo;
+                    org = V3(cam.cam_pos[0], cam.cam_pos[1], cam.cam_pos[2]) - dofo;
                     prev_id = -1;
                     prev_mat = -1;
-                    ior = a.atmo.ior;
+                    ior = atmo.ior;
                     in_solid = false;
                     thr = V3(1.f, 1.f, 1.f);
                     inc = V3(0.f, 0.f, 0.f);

@@ -163,14 +163,15 @@ __global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const 
 // order, with the reference's expressions (raytracer.fs.glsl:1012-1021: running mean with weight
 // 1/pass; RT_ACCUM_SUM adds instead).  Streams n_passes x 12 B per pixel once.
 __global__ __launch_bounds__(256) void k_accumulate(const float* totals, float* accum, size_t n_px, uint32_t first_pass,
-                                                    uint32_t n_passes, uint32_t pass_stride, int sum_mode) {
+                                                    uint32_t n_passes, uint32_t pass_stride, int rays_per_pixel, int sum_mode) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_px) return;
     float* acc = accum + i * 3;
     v3 col = V3(acc[0], acc[1], acc[2]);
     for (uint32_t p = 0; p < n_passes; p++) {
         const float* t = totals + ((size_t)p * n_px + i) * 3;
-        const v3 total = V3(t[0], t[1], t[2]);
+        const float rpp = (float)rays_per_pixel;
+        const v3 total = V3(t[0] / rpp, t[1] / rpp, t[2] / rpp);     // :1009
         if (sum_mode) col = col + total;
         else {
             const float w = 1.0f / (float)(first_pass + p * pass_stride), om = 1.0f - w;
@@ -372,7 +373,7 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
 template <bool STATS, bool CULL, bool FIRST>
 int launch_one(rt_ctx* c, const TraceArgs& a, int key) {
     // dynamic LDS: root table + per-lane node stack and leaf queue (+ the entry-distance plane when culling)
-    const size_t lds = (size_t)2 * c->n_meshes * sizeof(float4) + (size_t)(c->stack_depth + RT_LQ) * RT_BLOCK * (CULL ? 6 : 4);
+    const size_t lds = ((size_t)2 * c->n_meshes + RT_PC_F4) * sizeof(float4) + (size_t)(c->stack_depth + RT_LQ) * RT_BLOCK * (CULL ? 6 : 4);
     if (c->lds_for[key] != lds || c->blocks_per_cu[key] <= 0) {
         int nb = 0;
         HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST>, RT_BLOCK, lds));
@@ -796,7 +797,7 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
         c->pending_events.push_back({e0, e1});
         c->st.launches++;
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, c->stream, c->totals.p, c->accum,
-                           (size_t)n_px, a.first_pass, a.n_passes, stride, a.sum_mode);
+                           (size_t)n_px, a.first_pass, a.n_passes, stride, rpp, a.sum_mode);
     }
     HIPCK(c, hipGetLastError());
     c->n_accum += n_passes;
