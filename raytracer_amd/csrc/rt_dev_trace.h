@@ -179,6 +179,7 @@ struct TraceArgs {
     int rays_per_pixel, max_bounces, sum_mode;
     int refill_below;             // traversal yields to the path block when fewer lanes than this traverse
     int node_bias;                // a node step is taken when cN + node_bias > cT
+    int burst8;                   // a triangle burst lasts while 8 * (lanes with leaf work) >= burst8 * (lanes traversing at the vote)
 };
 
 // material index encoding: -1 atmosphere (kernel argument), [0,256) mesh, 256+i sphere i
@@ -273,6 +274,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     int prev_id = -1, prev_mat = -1, bounce = 0;
     float ior = 1.0f;
     bool in_solid = false;
+    int hb_key = 0, hb_msk = RT_TFB_BIT;   // hitBehind test of the ray in flight (set at query start)
     Trav tv;
     tv.cur = RT_NONE; tv.sp = 0; tv.lq = 0; tv.k = -1; tv.chunk = 0; tv.mask = 0; tv.node_live = false;
     tv.best_t = 1e20f; tv.best_rank = RT_MISS_RANK;
@@ -288,7 +290,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             if (cAny == 0) break;
             if (cAny < a.refill_below && __ballot(mode == M_PATH) != 0) break;
             const bool do_node = cT == 0 || (cN > 0 && cN + a.node_bias > cT);   // never a step without lanes
-            if (STATS) { if (do_node) { sch.node_steps++; sch.node_lanes += cN; } else { sch.tri_steps++; sch.tri_lanes += cT; } }
+            if (STATS && do_node) { sch.node_steps++; sch.node_lanes += cN; }
             if (do_node) {
                 if (can_node) {
                     if (tv.cur == RT_NONE) {
@@ -317,7 +319,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         }
                     }
                     if (tv.cur != RT_NONE) {                        // :562-584, both children of `cur`
-                        const float4* n = S.nodes + 4 * (size_t)tv.cur;
+                        const float4* n = (const float4*)((const char*)S.nodes + ((uint32_t)tv.cur << 6));
                         const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
                         const int ref1 = __float_as_int(n0.w), ref2 = __float_as_int(n1.w);
                         float t1a, t1b, t2a, t2b;
@@ -357,44 +359,54 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     }
                 }
             } else {
-                if (has_leaf) {
-                    if (tv.k < 0) {                                 // take up the most recently found leaf
-                        tv.lq--;
-                        const int ref = s_leaf[tv.lq * RT_BLOCK];
-                        tv.k = ~ref;
-                        if (CULL && unpack_dist(s_leaf_t[tv.lq * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS)
-                            tv.k = -1;
-                    }
-                    if (tv.k >= 0) {                                // one triangle of the leaf (:593-630)
-                        const float4* g = S.tri_geo + 4 * (size_t)tv.k;
-                        const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
-                        // all rejects are folded into one predicate and the three edge tests run together:
-                        // one divergent region instead of five nested ones (scalar-unit pressure)
-                        const bool tested = __float_as_int(g3.z) != prev_id;
-                        if (STATS) cnt.tri += tested;
-                        // hitBehind for this triangle's mesh (:605-615; in a solid: same mesh only [9.6])
-                        const int mw = __float_as_int(g3.w);
-                        const bool hb = in_solid ? ((mw & ~RT_TFB_BIT) == prev_mat) : ((mw & RT_TFB_BIT) == 0);
-                        const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
-                        const v3 N = V3(g0.w, g1.w, g2.w);
-                        const float nd = dot3(N, dir);
-                        const float t = -(dot3(N, org) + g3.x) / nd;
-                        bool ok = tested && !(__builtin_fabsf(nd) < 1e-6f) && !(nd > 0.0f && !hb);
-                        ok = ok && !(t < 1e-6f);                        // covers the reference's `t < 0` reject too
-                        // closer than (or tied with a later-ranked) current best; NaN t never wins
-                        ok = ok && (t < tv.best_t || (t == tv.best_t && tv.k < tv.best_rank));
-                        if (ok) {
-                            const v3 P = madd3(org, t, dir);
-                            const float e0 = dot3(N, cross3(B - A, P - A));
-                            const float e1 = dot3(N, cross3(C - B, P - B));
-                            const float e2 = dot3(N, cross3(A - C, P - C));
-                            const bool inside = !(e0 < 0.0f) && !(e1 < 0.0f) && !(e2 < 0.0f);
-                            tv.best_t = inside ? t : tv.best_t;
-                            tv.best_rank = inside ? tv.k : tv.best_rank;
+                // triangle burst: stay on triangles while at least half of the lanes that were
+                // traversing at the vote still have leaf work (an upper bound of the lanes a node
+                // step could serve then outnumbers them and the full vote is taken again)
+                const int lim = cN + cT;
+                int cTn;
+                do {
+                    if (STATS) { sch.tri_steps++; sch.tri_lanes += __popcll(__ballot(tv.k >= 0 || tv.lq > 0)); }
+                    if (tv.k >= 0 || tv.lq > 0) {
+                        if (tv.k < 0) {                                 // take up the most recently found leaf
+                            tv.lq--;
+                            const int ref = s_leaf[tv.lq * RT_BLOCK];
+                            tv.k = ~ref;
+                            if (CULL && unpack_dist(s_leaf_t[tv.lq * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS)
+                                tv.k = -1;
                         }
-                        tv.k = __float_as_int(g3.y) > 0 ? tv.k + 1 : -1;
+                        if (tv.k >= 0) {                                // one triangle of the leaf (:593-630)
+                            // 32-bit byte offset from a uniform base: one shift, no 64-bit address arithmetic
+                            const float4* g = (const float4*)((const char*)S.tri_geo + ((uint32_t)tv.k << 6));
+                            const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+                            // all rejects are folded into one predicate and the three edge tests run together:
+                            // one divergent region instead of five nested ones (scalar-unit pressure)
+                            const bool tested = __float_as_int(g3.z) != prev_id;
+                            if (STATS) cnt.tri += tested;
+                            // hitBehind for this triangle's mesh (:605-615; in a solid: same mesh only [9.6])
+                            // = in_solid ? mesh == prev_mesh : !transparentFromBehind, through the per-ray key/mask
+                            const bool hb = ((__float_as_int(g3.w) ^ hb_key) & hb_msk) == 0;
+                            const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
+                            const v3 N = V3(g0.w, g1.w, g2.w);
+                            const float nd = dot3(N, dir);
+                            const float t = -(dot3(N, org) + g3.x) / nd;
+                            bool ok = tested && !(__builtin_fabsf(nd) < 1e-6f) && !(nd > 0.0f && !hb);
+                            ok = ok && !(t < 1e-6f);                        // covers the reference's `t < 0` reject too
+                            // closer than (or tied with a later-ranked) current best; NaN t never wins
+                            ok = ok && (t < tv.best_t || (t == tv.best_t && tv.k < tv.best_rank));
+                            if (ok) {
+                                const v3 P = madd3(org, t, dir);
+                                const float e0 = dot3(N, cross3(B - A, P - A));
+                                const float e1 = dot3(N, cross3(C - B, P - B));
+                                const float e2 = dot3(N, cross3(A - C, P - C));
+                                const bool inside = !(e0 < 0.0f) && !(e1 < 0.0f) && !(e2 < 0.0f);
+                                tv.best_t = inside ? t : tv.best_t;
+                                tv.best_rank = inside ? tv.k : tv.best_rank;
+                            }
+                            tv.k = __float_as_int(g3.y) > 0 ? tv.k + 1 : -1;
+                        }
                     }
-                }
+                    cTn = __popcll(__ballot(tv.k >= 0 || tv.lq > 0));
+                } while (cTn > 0 && 8 * cTn >= a.burst8 * lim);
             }
         }
         if (__ballot(mode == M_PATH) == 0) break;                  // every lane is M_DONE
@@ -588,6 +600,10 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 inv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
                 tv.best_t = 1e20f;
                 tv.best_rank = RT_MISS_RANK;
+                // in a solid only the mesh the ray is inside shows its back faces (prev_mat = -1 or a
+                // sphere never equals a mesh index); outside, every mesh that is not transparentFromBehind
+                hb_key = in_solid ? prev_mat : 0;
+                hb_msk = in_solid ? ~RT_TFB_BIT : RT_TFB_BIT;
                 for (int i = 0; i < S.n_spheres; i++) {
                     const SphereDev& sph = S.spheres[i];
                     const v3 c = V3(sph.position[0], sph.position[1], sph.position[2]);

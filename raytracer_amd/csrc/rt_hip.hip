@@ -255,6 +255,7 @@ struct rt_ctx {
     bool flags_pending = false;           // materials changed since the triangle flag words were written
     bool cull = false;                    // conservative distance culling (rt_set_cull)
     int node_bias = 0;
+    int burst8 = 4;
     int refill_below = 0;                 // lanes still traversing below which a wave shades/refills; 0 = measured default
     // camera / image
     DevCamera cam{};
@@ -367,6 +368,7 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.n_by = (uint32_t)(c->cam.height + 15) / 16;
     a.n_chunks = 0;
     a.node_bias = c->node_bias;
+    a.burst8 = c->burst8;
     a.refill_below = c->refill_below > 0 ? c->refill_below : (c->cull ? 16 : 32);   // best measured, DESIGN.md 5
 }
 
@@ -441,6 +443,7 @@ int rt_create(int device, rt_ctx** out) {
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
     c->stream = c->own_stream;
     if (const char* e = getenv("RT_NODE_BIAS")) c->node_bias = atoi(e);
+    if (const char* e = getenv("RT_BURST8")) c->burst8 = std::max(0, std::min(64, atoi(e)));
     if (const char* e = getenv("RT_REFILL_BELOW")) c->refill_below = std::max(1, std::min(64, atoi(e)));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
@@ -487,6 +490,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
         (n_spheres && !spheres96) || !atmosphere80)
         return fail(c, RT_E_ARG, "null buffer with non-zero count");
     if (n_meshes > 256 || n_spheres > 256) return fail(c, RT_E_LIMIT, "more than 256 meshes/spheres");
+    if (n_tris > (1 << 25) || n_nodes > (1 << 25)) return fail(c, RT_E_LIMIT, "more than 2^25 triangles or nodes (32-bit record offsets)");
     HIPCK(c, hipSetDevice(c->device));
     const Std140Tri* tris = (const Std140Tri*)tris28;
     const Std140Mesh* meshes = (const Std140Mesh*)meshes128;
