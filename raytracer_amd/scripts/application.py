@@ -138,6 +138,25 @@ class Application:
             self.display_program.configure_buffers_and_uniforms(self.display_scene)
 
 
+def write_pfm(path, img_bottom_up: np.ndarray) -> None:
+    """Portable float map, RGB, little-endian (negative scale), rows bottom-to-top."""
+    img = np.ascontiguousarray(img_bottom_up, dtype="<f4")
+    h, w, c = img.shape
+    assert c == 3
+    with open(path, "wb") as f:
+        f.write(f"PF\n{w} {h}\n-1.0\n".encode("ascii"))
+        f.write(img.tobytes())
+
+
+def read_pfm(path) -> np.ndarray:
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = (int(x) for x in f.readline().split())
+        scale = float(f.readline())
+        data = np.frombuffer(f.read(), dtype="<f4" if scale < 0 else ">f4")
+    return data.reshape(h, w, 3)
+
+
 class ProgramABC(ABC):
     """Plugin interface of a render program (application.py:475-611)."""
 
@@ -265,7 +284,9 @@ class RayTracerDynamic(ProgramABC):
 
     # -- application.py:1094-1126 -------------------------------------------------------------
     def save_frame(self, fbo, frame, cycle) -> None:
-        """PNG (clip -> *255 -> uint8, row 0 = top) + raw float32 .npy (the reference writes EXR via imageio)."""
+        """PNG (clip -> *255 -> uint8, row 0 = top, application.py:1104-1117) + the float32 image as
+        .npy and as PFM (the reference writes EXR via imageio, :1118-1126, which is absent here;
+        PFM is the HDR format that needs no library: bottom-up scanlines, like fbo.read)."""
         from PIL import Image
 
         if not hasattr(self, "target_dir"):
@@ -277,6 +298,7 @@ class RayTracerDynamic(ProgramABC):
         stem = f"f{frame:05}_c{cycle:05}"
         Image.fromarray(rgb8, "RGB").save(self.target_dir / f"{stem}_f1.png")
         np.save(self.target_dir / f"{stem}_f4.npy", flipped)
+        write_pfm(self.target_dir / f"{stem}_f4.pfm", hdr)
 
     def handle_event(self, event, app, cam, scene, keyboard_enabled, mouse_enabled):
         return

@@ -51,6 +51,12 @@ def test_headless_loop_with_checker_backend(oracle_lib, tmp_path):
     pngs = sorted(p.name for p in prog.target_dir.glob("f00002_*.png"))
     assert pngs == [f"f00002_c{c:05}_f1.png" for c in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10)]
     assert prog.last_image.shape == (18, 32, 3) and prog.last_image.max() > 0
+    # HDR dumps: .npy is top-down like the PNG, .pfm bottom-up like fbo.read; same numbers
+    from raytracer_amd.scripts.application import read_pfm
+
+    npy = np.load(prog.target_dir / "f00002_c00010_f4.npy")
+    pfm = read_pfm(prog.target_dir / "f00002_c00010_f4.pfm")
+    assert np.array_equal(np.flip(npy, axis=0).view(np.uint32), pfm.view(np.uint32))
     # the segmented running mean equals one uninterrupted render of the same passes
     from conftest import make_ctx
 
