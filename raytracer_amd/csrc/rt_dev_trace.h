@@ -217,22 +217,40 @@ struct Trav {
 // root box the ray's line touches.  A leaf root is tested as the reference does (:586); for an
 // interior root the test is an exact shortcut: child boxes nest inside it and float
 // subtract/multiply are monotonic, so no child test could pass when the root test fails.
+template <bool STATS, bool CULL, bool FINITE>
+__device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn, v3 org, v3 inv, float best_t, Counters& cnt) {
+    uint32_t mask = 0;
+    // three boxes per trip: their six LDS reads are in flight together (one exposed LDS latency
+    // per trip instead of one per mesh); the tail re-reads the last box and masks its bit off
+    for (int b0 = 0; b0 < jn; b0 += 3) {
+        float4 lo[3], hi[3];
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int j = min(b0 + u, jn - 1);
+            lo[u] = s_roots[2 * j];
+            hi[u] = s_roots[2 * j + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            float ta, tb;
+            const bool h = FINITE ? box_test_finite(org, inv, lo[u], hi[u], ta, tb) : box_test(org, inv, lo[u], hi[u], ta, tb);
+            const bool real = __float_as_int(lo[u].w) != RT_NONE && b0 + u < jn;
+            const bool take = real && h && !culled<CULL>(ta, tb, best_t);
+            if (STATS) cnt.box += real;
+            mask |= take ? (1u << (b0 + u)) : 0u;
+        }
+    }
+    return mask;
+}
+
 template <bool STATS, bool CULL>
 __device__ __forceinline__ uint32_t root_mask(const DevScene& S, const float4* s_roots, int chunk, v3 org, v3 inv, float best_t,
                                               Counters& cnt) {
-    uint32_t mask = 0;
     const int jn = min(32, S.n_meshes - chunk * 32);
     // wave-uniform choice of the slab-test form (see box_test_finite)
     const bool all_finite = __ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0;
-    for (int b = 0; b < jn; b++) {
-        const float4 lo = s_roots[2 * (chunk * 32 + b)], hi = s_roots[2 * (chunk * 32 + b) + 1];
-        float ta, tb;
-        const bool h = all_finite ? box_test_finite(org, inv, lo, hi, ta, tb) : box_test(org, inv, lo, hi, ta, tb);
-        const bool take = __float_as_int(lo.w) != RT_NONE && h && !culled<CULL>(ta, tb, best_t);
-        if (STATS) cnt.box += __float_as_int(lo.w) != RT_NONE;
-        mask |= take ? (1u << b) : 0u;
-    }
-    return mask;
+    return all_finite ? root_mask_loop<STATS, CULL, true>(s_roots + 64 * chunk, jn, org, inv, best_t, cnt)
+                      : root_mask_loop<STATS, CULL, false>(s_roots + 64 * chunk, jn, org, inv, best_t, cnt);
 }
 
 template <bool STATS, bool CULL, bool FIRST_HIT>
@@ -368,6 +386,9 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         }
                         tv.cur = in_n ? rn : (in_f ? rf : RT_NONE);
                     }
+                    // nothing in hand, nothing deferred, no root left: node work is over now, not
+                    // one step later (saves one node step per ray)
+                    if (tv.cur == RT_NONE && tv.sp == 0 && tv.mask == 0 && (tv.chunk + 1) * 32 >= S.n_meshes) tv.node_live = false;
                 }
             } else {
                 // triangle burst: stay on triangles while at least half of the lanes that were
@@ -634,7 +655,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 tv.cur = RT_NONE;
                 tv.chunk = 0;
                 tv.mask = root_mask<STATS, CULL>(S, s_roots, 0, org, inv, tv.best_t, cnt);
-                tv.node_live = true;
+                tv.node_live = tv.mask != 0 || S.n_meshes > 32;
                 mode = M_TRAV;
             }
         }
