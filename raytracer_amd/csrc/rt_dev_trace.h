@@ -12,27 +12,30 @@
 //
 // Data layout in HBM (built by rt_set_scene, refreshed by the prep kernels):
 //   tri_geo  4 x float4 per triangle SLOT (64 B, one half cache line):
-//              {A.xyz, N.x} {B.xyz, N.y} {C.xyz, N.z} {d, bits(rem), bits(triId), 0}
+//              {A.xyz, N.x} {B.xyz, N.y} {C.xyz, N.z} {d, bits(rem), bits(triId), bits(flags)}
 //            slots are in traversal order of the reference (mesh ascending, depth-first,
 //            second child first, leaf order), so (a) every leaf and every subtree is one
 //            contiguous range, (b) the slot index is the rank that decides ties exactly as
 //            the reference's "first found wins" (strict <, :625) whatever order the kernel
-//            visits nodes in.  rem = triangles left in the leaf after this one.
+//            visits nodes in.  rem = triangles left in the leaf after this one;
+//            flags = mesh index | RT_TFB_BIT (the mesh's transparentFromBehind).
 //   tri_nrm  3 x float4 per slot (corner normals; .w of the first = mesh index).
 //   nodes    4 x float4 per INTERIOR node: both children's boxes and references
 //              {lo1.xyz, bits(ref1)} {hi1.xyz, bits(ref2)} {lo2.xyz, 0} {hi2.xyz, 0}
 //            ref >= 0: interior record index; ref < 0 and != RT_NONE: leaf, first slot = ~ref.
 //   roots    2 x float4 per mesh: {lo.xyz, bits(ref)} {hi.xyz, 0} of the mesh's root node.
 //   mats     the 80-byte std140 Material of every mesh, as uploaded.
+//   totals   one float3 per (pass, pixel) of the launch: k_trace writes, k_accumulate folds.
 //
-// Execution model: every lane owns one pixel and runs a small state machine.  In the
-// traversal phase the wave votes (ballot + popcount) between "one interior node" and "one
-// triangle" and executes the block more lanes are waiting for; when fewer than
-// `refill_below` lanes are still traversing, the waiting lanes shade their hits and start
-// their next ray (next bounce, next sample or next pass) in one path block.  A block thus
-// runs with a well-filled EXEC mask instead of the 20 % lane utilisation a nested per-lane
-// loop nest measures here (profiles/pmc_r1a).  The order of operations seen by any one lane is
-// unchanged, so results do not depend on the votes.
+// Execution model: persistent waves take chunks of 256 samples (one pass over a
+// 16x16 pixel block) from a launch-wide counter; every lane runs one sample at a time and takes
+// the next one of its wave's chunk when it is done.  A lane holds node work (record in hand,
+// node stack, mesh roots to visit) and leaf work (triangle in progress, 2-entry leaf queue) at
+// once; the wave votes (ballot + popcount) between a node step and a triangle step, runs
+// triangle steps in bursts, and when fewer than `refill_below` lanes still traverse, the lanes
+// that wait shade their hit and start their next ray in one path block.  The order in which a
+// lane meets its boxes and triangles changes with the votes; the result does not: it is the
+// minimum of (t, slot rank) over the same set of tests.
 #pragma once
 #include "rt_dev_math.h"
 
