@@ -165,7 +165,9 @@ int rt_get_stats(rt_ctx* ctx, rt_stats_t* out);
 
 /* launch on a caller-provided hipStream_t (e.g. torch's current stream, so that a
  * torch.distributed all-reduce of the bound accumulator is ordered after the render
- * without a host sync); NULL returns to the context's own stream.  Oracle: no-op. */
+ * without a host sync).  NULL is HIP's null (legacy default) stream - which is what torch's
+ * default stream is; RT_STREAM_OWN returns to the context's own stream.  Oracle: no-op. */
+#define RT_STREAM_OWN ((void*)(intptr_t)-1)
 int rt_set_stream(rt_ctx* ctx, void* hip_stream);
 /* block until all work of the context is done (hipStreamSynchronize) */
 int rt_sync(rt_ctx* ctx);

@@ -924,7 +924,7 @@ int rt_set_stream(rt_ctx* c, void* s) {
     int rc = resolve_events(c);          // events belong to the old stream
     if (rc) return rc;
     HIPCK(c, hipStreamSynchronize(c->stream));
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (s == RT_STREAM_OWN) ? c->own_stream : (hipStream_t)s;   // NULL = the null stream
     return RT_OK;
 }
 

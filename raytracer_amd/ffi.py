@@ -268,7 +268,10 @@ class RtContext:
         self._ck(self.lib.dll.rt_sync(self._h), "rt_sync")
 
     def set_stream(self, hip_stream: int | None) -> None:
-        self._ck(self.lib.dll.rt_set_stream(self._h, _vp(hip_stream) if hip_stream else None), "rt_set_stream")
+        """hip_stream = a hipStream_t handle; 0 = HIP's null stream (torch's default stream);
+        None = back to the context's own stream."""
+        h = _vp(-1) if hip_stream is None else _vp(hip_stream)     # RT_STREAM_OWN = (void*)-1
+        self._ck(self.lib.dll.rt_set_stream(self._h, h), "rt_set_stream")
 
     def stream(self) -> int:
         return int(self.lib.dll.rt_stream(self._h) or 0)
