@@ -59,10 +59,20 @@ def main() -> None:
     from raytracer_amd import ffi
     from raytracer_amd.scripts.scenes import final_scene_numba as S
 
+    # RT_BENCH_BACKEND=gloo + fewer GPUs than ranks is a rehearsal of the N > 1 code path on a
+    # one-GPU box (ranks share the card); the real run is nccl (= RCCL), one GPU per rank
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"{world} ranks but {n_dev} GPUs")
+    local_rank %= max(n_dev, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
