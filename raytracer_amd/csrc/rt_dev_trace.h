@@ -120,8 +120,8 @@ __device__ __forceinline__ bool box_test(v3 o, v3 inv, float4 lo, float4 hi, flo
 // exactly zero direction component): no slab value can then be NaN (finite*finite, or
 // +-inf from overflow), and for non-NaN values the reference's compare-and-swap ladder is
 // exactly  max(entry_x, entry_y, entry_z) <= min(exit_x, exit_y, exit_z)  with per-axis
-// entry/exit = min/max of the two slab values (proof: DESIGN.md 5).  v_min/v_max/v_max3/v_min3
-// issue in 2 cycles where a v_cmp + v_cndmask pair takes 8 (tools/ubench/valu_rate.hip).
+// entry/exit = min/max of the two slab values (proof: DESIGN.md 5).  A v_min/v_max costs 4.7
+// cycles where the v_cmp + v_cndmask pair of a ladder step costs 8.2 (tools/ubench/valu_rate.hip).
 __device__ __forceinline__ bool box_test_finite(v3 o, v3 inv, float4 lo, float4 hi, float& tmin_out, float& tmax_out) {
     const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
     const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;

@@ -17,6 +17,23 @@ __global__ __launch_bounds__(256) void k(float* out, float a, float b, int n) {
             } else if (KIND == 2) { // compare + select (v_cmp + v_cndmask)
                 x0 = x0 > x1 ? x2 : x0; x1 = x1 > x2 ? x3 : x1; x2 = x2 > x3 ? x4 : x2; x3 = x3 > x4 ? x5 : x3;
                 x4 = x4 > x5 ? x6 : x4; x5 = x5 > x6 ? x7 : x5; x6 = x6 > x7 ? x0 : x6; x7 = x7 > x0 ? x1 : x7;
+            } else if (KIND == 4) { // v_pk_fma_f32: two f32 FMAs per lane per instruction
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                f2 p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, a2 = {a, a}, b2 = {b, b};
+                p0 = __builtin_elementwise_fma(p0, a2, b2); p1 = __builtin_elementwise_fma(p1, a2, b2);
+                p2 = __builtin_elementwise_fma(p2, a2, b2); p3 = __builtin_elementwise_fma(p3, a2, b2);
+                p0 = __builtin_elementwise_fma(p0, a2, b2); p1 = __builtin_elementwise_fma(p1, a2, b2);
+                p2 = __builtin_elementwise_fma(p2, a2, b2); p3 = __builtin_elementwise_fma(p3, a2, b2);
+                x0 = p0.x; x1 = p0.y; x2 = p1.x; x3 = p1.y; x4 = p2.x; x5 = p2.y; x6 = p3.x; x7 = p3.y;
+            } else if (KIND == 5) { // v_min_f32 / v_max_f32
+                x0 = __builtin_fminf(x0, x1); x1 = __builtin_fmaxf(x1, x2); x2 = __builtin_fminf(x2, x3); x3 = __builtin_fmaxf(x3, x4);
+                x4 = __builtin_fminf(x4, x5); x5 = __builtin_fmaxf(x5, x6); x6 = __builtin_fminf(x6, x7); x7 = __builtin_fmaxf(x7, x0);
+            } else if (KIND == 6) { // v_mul_lo_u32
+                unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1), u2 = __float_as_uint(x2), u3 = __float_as_uint(x3);
+                unsigned u4 = __float_as_uint(x4), u5 = __float_as_uint(x5), u6 = __float_as_uint(x6), u7 = __float_as_uint(x7);
+                u0 *= u1; u1 *= u2; u2 *= u3; u3 *= u4; u4 *= u5; u5 *= u6; u6 *= u7; u7 *= u0;
+                x0 = __uint_as_float(u0); x1 = __uint_as_float(u1); x2 = __uint_as_float(u2); x3 = __uint_as_float(u3);
+                x4 = __uint_as_float(u4); x5 = __uint_as_float(u5); x6 = __uint_as_float(u6); x7 = __uint_as_float(u7);
             } else {                // IEEE division
                 x0 = x0 / a; x1 = x1 / a; x2 = x2 / a; x3 = x3 / a; x4 = x4 / a; x5 = x5 / a; x6 = x6 / a; x7 = x7 / a;
             }
@@ -45,6 +62,9 @@ int main() {
         run<1>("v_mul/v_add", 64, w);
         run<2>("v_cmp+v_cndmask (x2)", 128, w);
         run<3>("IEEE div (per div)", 64, w);
+        run<4>("v_pk_fma_f32", 64, w);
+        run<5>("v_min/v_max_f32", 64, w);
+        run<6>("v_mul_lo_u32", 64, w);
     }
     return 0;
 }
