@@ -82,6 +82,7 @@ struct DevScene {
     int n_meshes;
     int n_spheres;
     int stack_depth;      // stack entries a lane can need (max tree depth + 1)
+    int tlas_root;        // > 32 meshes: record of the top-level tree over the mesh roots; else -1 (roots in LDS)
 };
 
 struct DevCamera {
@@ -166,9 +167,6 @@ __device__ __forceinline__ v3 view_point_of(const DevCamera& cam, int px, int py
     return V3(r[0], r[1], r[2]);
 }
 
-struct PathConsts { DevCamera cam; MatDev atmo; };
-#define RT_PC_F4 ((int)((sizeof(PathConsts) + 15) / 16))   // float4 slots of LDS it takes
-
 enum { M_TRAV = 0, M_PATH = 2, M_DONE = 3 };
 
 // deferred leaves a lane can hold (the leaf queue); a lane joins a node step only while two
@@ -196,6 +194,12 @@ struct TraceArgs {
     int burst8;                   // a triangle burst lasts while 8 * (lanes with leaf work) >= burst8 * (lanes traversing at the vote)
 };
 
+// Everything only the path block reads (camera, atmosphere, sampling parameters, output and
+// material pointers) is read from an LDS copy of the kernel arguments there: held in scalar
+// registers across the traversal loop it costs ~70 SGPRs and spills.
+struct PathConsts { TraceArgs a; };
+#define RT_PC_F4 ((int)((sizeof(PathConsts) + 15) / 16))   // float4 slots of LDS it takes
+
 // material index encoding: -1 atmosphere (kernel argument), [0,256) mesh, 256+i sphere i
 __device__ __forceinline__ const MatDev* material_of(const DevScene& S, int idx) {
     return idx < 256 ? &S.mats[idx] : &S.spheres[idx - 256].material;
@@ -209,32 +213,31 @@ struct Trav {
     int sp;           // node stack entries
     int lq;           // leaf queue entries
     int k;            // triangle slot in progress, or -1
-    int chunk;        // group of 32 meshes whose roots are in `mask`
-    uint32_t mask;    // roots of that group still to visit
-    bool node_live;   // node work may remain (cleared when the last root group is exhausted)
+    uint32_t mask;    // mesh roots still to visit (scenes of up to 32 meshes; larger ones start at the top-level tree)
+    bool node_live;   // node work may remain
     float best_t;
     int best_rank;
 };
 
-// Root boxes of one group of up to 32 meshes (LDS broadcast reads) -> bit mask of the meshes whose
+// Root boxes of a scene of up to 32 meshes (LDS broadcast reads) -> bit mask of the meshes whose
 // root box the ray's line touches.  A leaf root is tested as the reference does (:586); for an
 // interior root the test is an exact shortcut: child boxes nest inside it and float
 // subtract/multiply are monotonic, so no child test could pass when the root test fails.
 template <bool STATS, bool CULL, bool FINITE>
 __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn, v3 org, v3 inv, float best_t, Counters& cnt) {
     uint32_t mask = 0;
-    // three boxes per trip: their six LDS reads are in flight together (one exposed LDS latency
+    // two boxes per trip: their four LDS reads are in flight together (one exposed LDS latency
     // per trip instead of one per mesh); the tail re-reads the last box and masks its bit off
-    for (int b0 = 0; b0 < jn; b0 += 3) {
-        float4 lo[3], hi[3];
+    for (int b0 = 0; b0 < jn; b0 += 2) {
+        float4 lo[2], hi[2];
 #pragma unroll
-        for (int u = 0; u < 3; u++) {
+        for (int u = 0; u < 2; u++) {
             const int j = min(b0 + u, jn - 1);
             lo[u] = s_roots[2 * j];
             hi[u] = s_roots[2 * j + 1];
         }
 #pragma unroll
-        for (int u = 0; u < 3; u++) {
+        for (int u = 0; u < 2; u++) {
             float ta, tb;
             const bool h = FINITE ? box_test_finite(org, inv, lo[u], hi[u], ta, tb) : box_test(org, inv, lo[u], hi[u], ta, tb);
             const bool real = __float_as_int(lo[u].w) != RT_NONE && b0 + u < jn;
@@ -247,13 +250,11 @@ __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn
 }
 
 template <bool STATS, bool CULL>
-__device__ __forceinline__ uint32_t root_mask(const DevScene& S, const float4* s_roots, int chunk, v3 org, v3 inv, float best_t,
-                                              Counters& cnt) {
-    const int jn = min(32, S.n_meshes - chunk * 32);
+__device__ __forceinline__ uint32_t root_mask(int jn, const float4* s_roots, v3 org, v3 inv, float best_t, Counters& cnt) {
     // wave-uniform choice of the slab-test form (see box_test_finite)
     const bool all_finite = __ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0;
-    return all_finite ? root_mask_loop<STATS, CULL, true>(s_roots + 64 * chunk, jn, org, inv, best_t, cnt)
-                      : root_mask_loop<STATS, CULL, false>(s_roots + 64 * chunk, jn, org, inv, best_t, cnt);
+    return all_finite ? root_mask_loop<STATS, CULL, true>(s_roots, jn, org, inv, best_t, cnt)
+                      : root_mask_loop<STATS, CULL, false>(s_roots, jn, org, inv, best_t, cnt);
 }
 
 template <bool STATS, bool CULL, bool FIRST_HIT>
@@ -261,14 +262,16 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     const DevScene& S = a.scene;
     // ---- LDS: mesh root table (2 float4 per mesh), then the per-lane columns
     float4* s_roots = s_mem;
-    const int n_root4 = 2 * S.n_meshes;
+    const int n_root4 = S.tlas_root >= 0 ? 0 : 2 * S.n_meshes;
     for (int i = threadIdx.x; i < n_root4; i += RT_BLOCK) s_roots[i] = S.roots[i];
     // camera and atmosphere constants: read from LDS where the path block needs them, instead of
     // ~50 scalar registers held (and spilled) across the traversal loop
     PathConsts* s_pc = (PathConsts*)(s_mem + n_root4);
-    if (threadIdx.x == 0) { s_pc->cam = a.cam; s_pc->atmo = a.atmo; }
-    const DevCamera& cam = s_pc->cam;
-    const MatDev& atmo = s_pc->atmo;
+    if (threadIdx.x == 0) s_pc->a = a;
+    const TraceArgs& P = s_pc->a;          // the LDS copy: use it wherever only the path block needs a value
+    const DevScene& PS = P.scene;
+    const DevCamera& cam = P.cam;
+    const MatDev& atmo = P.atmo;
     // per-lane column: node stack entries [0, stack_depth), leaf queue [stack_depth, stack_depth + RT_LQ);
     // entry e at s_stack[e * RT_BLOCK].  CULL builds keep the entry distance of each deferred
     // child in a second plane so that it can be re-culled when it is taken up.
@@ -308,7 +311,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     bool in_solid = false;
     int hb_key = 0, hb_msk = RT_TFB_BIT;   // hitBehind test of the ray in flight (set at query start)
     Trav tv;
-    tv.cur = RT_NONE; tv.sp = 0; tv.lq = 0; tv.k = -1; tv.chunk = 0; tv.mask = 0; tv.node_live = false;
+    tv.cur = RT_NONE; tv.sp = 0; tv.lq = 0; tv.k = -1; tv.mask = 0; tv.node_live = false;
     tv.best_t = 1e20f; tv.best_rank = RT_MISS_RANK;
 
     while (true) {
@@ -336,18 +339,15 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         } else if (tv.mask) {
                             const int b = __builtin_ctz(tv.mask);
                             tv.mask &= tv.mask - 1;
-                            const int ref = __float_as_int(s_roots[2 * (tv.chunk * 32 + b)].w);
+                            const int ref = __float_as_int(s_roots[2 * b].w);
                             if (ref >= 0) tv.cur = ref;
                             else {                                  // the mesh's root node is a leaf (:586)
                                 s_leaf[tv.lq * RT_BLOCK] = ref;
                                 if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = 0;   // distance 0: never culled
                                 tv.lq++;
                             }
-                        } else if ((tv.chunk + 1) * 32 >= S.n_meshes) {
+                        } else {
                             tv.node_live = false;
-                        } else {                                    // more than 32 meshes: next group of roots
-                            tv.chunk++;
-                            tv.mask = root_mask<STATS, CULL>(S, s_roots, tv.chunk, org, inv, tv.best_t, cnt);
                         }
                     }
                     if (tv.cur != RT_NONE) {                        // :562-584, both children of `cur`
@@ -391,7 +391,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     }
                     // nothing in hand, nothing deferred, no root left: node work is over now, not
                     // one step later (saves one node step per ray)
-                    if (tv.cur == RT_NONE && tv.sp == 0 && tv.mask == 0 && (tv.chunk + 1) * 32 >= S.n_meshes) tv.node_live = false;
+                    if (tv.cur == RT_NONE && tv.sp == 0 && tv.mask == 0) tv.node_live = false;
                 }
             } else {
                 // triangle burst: stay on triangles while at least half of the lanes that were
@@ -458,8 +458,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         else id = __float_as_int(S.tri_geo[4 * (size_t)tv.best_rank + 3].z);
                     }
                     const size_t pix = (size_t)(pxy >> 16) * cam.width + (pxy & 0xffffu);
-                    a.ids[pix] = id;
-                    a.ts[pix] = tv.best_t;
+                    P.ids[pix] = id;
+                    P.ts[pix] = tv.best_t;
                     have = false;
                     fresh = true;
                     s = 0;
@@ -475,7 +475,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     int hit_id = -1, hit_mat;
                     if (tv.best_rank < 0) {
                         const int si = tv.best_rank - RT_SPHERE_RANK;
-                        const SphereDev& sph = S.spheres[si];
+                        const SphereDev& sph = PS.spheres[si];
                         normal = normalize3(hit_point - V3(sph.position[0], sph.position[1], sph.position[2]));
                         hit_mat = 256 + si;
                     } else {
@@ -488,20 +488,20 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         const float w = length3(cross3(B - A, hit_point - A)) / 2.0f / area;
                         const float u = length3(cross3(C - B, hit_point - B)) / 2.0f / area;
                         const float v = 1.0f - u - w;
-                        const float4* nn = S.tri_nrm + 3 * (size_t)tv.best_rank;
+                        const float4* nn = PS.tri_nrm + 3 * (size_t)tv.best_rank;
                         const float4 na = nn[0], nb = nn[1], nc = nn[2];
                         normal = V3(na.x * u + nb.x * v + nc.x * w, na.y * u + nb.y * v + nc.y * w,
                                     na.z * u + nb.z * v + nc.z * w);
                         hit_id = __float_as_int(g3.z);
                         hit_mat = __float_as_int(na.w);
                     }
-                    const MatDev* m = material_of(S, hit_mat);
+                    const MatDev* m = material_of(PS, hit_mat);
                     const float alpha = m->color[3];
                     bool ended = false, passthrough = false;
                     if (alpha < 0.99999f) {                        // :725-736
                         if (random_value(rng) > alpha) {
                             passthrough = true;
-                            if (bounce == a.max_bounces) ended = true;
+                            if (bounce == P.max_bounces) ended = true;
                             else { org = hit_point; prev_id = hit_id; prev_mat = hit_mat; }
                         }
                     }
@@ -529,7 +529,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 float pc0 = atmo.color[0], pc1 = atmo.color[1], pc2 = atmo.color[2];
                                 float pc3 = atmo.color[3], ptr = atmo.transmission;
                                 if (prev_mat >= 0) {
-                                    const MatDev* pm = material_of(S, prev_mat);
+                                    const MatDev* pm = material_of(PS, prev_mat);
                                     pc0 = pm->color[0]; pc1 = pm->color[1]; pc2 = pm->color[2]; pc3 = pm->color[3];
                                     ptr = pm->transmission;
                                 }
@@ -548,7 +548,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             spec_dir = reflect3(dir, nrm);
                             diffuse = -diffuse;
                         }
-                        if (bounce == a.max_bounces) ended = true;
+                        if (bounce == P.max_bounces) ended = true;
                         else {
                             org = hit_point;
                             if (specular) {
@@ -570,10 +570,10 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 if (fresh && !FIRST_HIT) {                         // the path is over (:989): totalIncomingLight += inc
                     // the sample's running sum lives in the radiance buffer (three fewer live registers);
                     // k_accumulate divides by RAYS_PER_PIXEL (:1009)
-                    float* o = a.totals + ((size_t)pass_no * n_px + (size_t)(pxy >> 16) * cam.width + (pxy & 0xffffu)) * 3;
+                    float* o = P.totals + ((size_t)pass_no * n_px + (size_t)(pxy >> 16) * cam.width + (pxy & 0xffffu)) * 3;
                     const v3 sum = s == 1 ? V3(0.f, 0.f, 0.f) : V3(o[0], o[1], o[2]);
                     o[0] = sum.x + inc.x; o[1] = sum.y + inc.y; o[2] = sum.z + inc.z;
-                    if (s == a.rays_per_pixel) { s = 0; have = false; }   // the sample is complete (:1008-1010)
+                    if (s == P.rays_per_pixel) { s = 0; have = false; }   // the sample is complete (:1008-1010)
                 }
             }
             need = fresh && !have;
@@ -583,13 +583,14 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             if (w_off == 256u) {
                 if (w_dry) { if (need) mode = M_DONE; break; }
                 unsigned int c = 0;
-                if (lane == 0) c = atomicAdd(a.work_counter, 1u);
+                if (lane == 0) c = atomicAdd(P.work_counter, 1u);
                 c = __builtin_amdgcn_readfirstlane(c);
-                if (c >= a.n_chunks) { w_dry = true; continue; }
-                const uint32_t per_pass = a.n_bx * a.n_by;
+                if (c >= (unsigned int)__builtin_amdgcn_readfirstlane((int)P.n_chunks)) { w_dry = true; continue; }
+                const uint32_t n_bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.n_bx);
+                const uint32_t per_pass = n_bx * (uint32_t)__builtin_amdgcn_readfirstlane((int)P.n_by);
                 w_pass = c / per_pass;
-                const uint32_t r = c - w_pass * per_pass, by = r / a.n_bx;
-                w_x0 = (int)((r - by * a.n_bx) * 16u);
+                const uint32_t r = c - w_pass * per_pass, by = r / n_bx;
+                w_x0 = (int)((r - by * n_bx) * 16u);
                 w_y0 = (int)(by * 16u);
                 w_off = 0;
             }
@@ -608,7 +609,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             if (fresh && have) {
                 {
                     const uint32_t pix = (pxy >> 16) * (uint32_t)cam.width + (pxy & 0xffffu);
-                    if (s == 0) rng = pix + (a.first_pass + pass_no * a.pass_stride) * 747796405u;   // :956-957
+                    if (s == 0) rng = pix + (P.first_pass + pass_no * P.pass_stride) * 747796405u;   // :956-957
                     const v3 view_point = view_point_of(cam, (int)(pxy & 0xffffu), (int)(pxy >> 16));
                     // camera sample (:972-987); four draws: DoF x,y then AA x,y
                     const float r1 = random_value(rng), r2 = random_value(rng), r3 = random_value(rng), r4 = random_value(rng);
@@ -639,8 +640,9 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 // sphere never equals a mesh index); outside, every mesh that is not transparentFromBehind
                 hb_key = in_solid ? prev_mat : 0;
                 hb_msk = in_solid ? ~RT_TFB_BIT : RT_TFB_BIT;
-                for (int i = 0; i < S.n_spheres; i++) {
-                    const SphereDev& sph = S.spheres[i];
+                const int n_sph = __builtin_amdgcn_readfirstlane(PS.n_spheres);
+                for (int i = 0; i < n_sph; i++) {
+                    const SphereDev& sph = PS.spheres[i];
                     const v3 c = V3(sph.position[0], sph.position[1], sph.position[2]);
                     const v3 oo = org - c;
                     const float qa = dot3(dir, dir);
@@ -655,10 +657,16 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 tv.sp = 0;
                 tv.lq = 0;
                 tv.k = -1;
-                tv.cur = RT_NONE;
-                tv.chunk = 0;
-                tv.mask = root_mask<STATS, CULL>(S, s_roots, 0, org, inv, tv.best_t, cnt);
-                tv.node_live = tv.mask != 0 || S.n_meshes > 32;
+                const int tlas = __builtin_amdgcn_readfirstlane(PS.tlas_root);
+                if (tlas >= 0) {                                   // many meshes: start at the top-level tree
+                    tv.cur = tlas;
+                    tv.mask = 0;
+                    tv.node_live = true;
+                } else {
+                    tv.cur = RT_NONE;
+                    tv.mask = root_mask<STATS, CULL>(__builtin_amdgcn_readfirstlane(PS.n_meshes), s_roots, org, inv, tv.best_t, cnt);
+                    tv.node_live = tv.mask != 0;
+                }
                 mode = M_TRAV;
             }
         }

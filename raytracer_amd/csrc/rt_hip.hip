@@ -15,6 +15,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.py).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -251,6 +252,7 @@ struct rt_ctx {
     MatDev atmo{};
     int n_tris = 0, n_slots = 0, n_meshes = 0, n_nodes = 0, n_visit = 0, n_rec = 0, n_spheres = 0;
     int stack_depth = 1;
+    int tlas_root = -1;                   // record of the top-level tree's root (scenes with > 32 meshes), else -1
     bool have_scene = false, have_cam = false, prep_pending = false;
     bool flags_pending = false;           // materials changed since the triangle flag words were written
     bool cull = false;                    // conservative distance culling (rt_set_cull)
@@ -351,6 +353,7 @@ DevScene scene_view(const rt_ctx* c) {
     s.tri_geo = c->geo.p; s.tri_nrm = c->nrm.p; s.nodes = c->nodes.p; s.roots = c->roots.p;
     s.mats = c->mats.p; s.spheres = c->spheres.p; s.n_meshes = c->n_meshes; s.n_spheres = c->n_spheres;
     s.stack_depth = c->stack_depth;
+    s.tlas_root = c->tlas_root;
     return s;
 }
 
@@ -375,7 +378,7 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
 template <bool STATS, bool CULL, bool FIRST>
 int launch_one(rt_ctx* c, const TraceArgs& a, int key) {
     // dynamic LDS: root table + per-lane node stack and leaf queue (+ the entry-distance plane when culling)
-    const size_t lds = ((size_t)2 * c->n_meshes + RT_PC_F4) * sizeof(float4) + (size_t)(c->stack_depth + RT_LQ) * RT_BLOCK * (CULL ? 6 : 4);
+    const size_t lds = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_meshes) + RT_PC_F4) * sizeof(float4) + (size_t)(c->stack_depth + RT_LQ) * RT_BLOCK * (CULL ? 6 : 4);
     if (c->lds_for[key] != lds || c->blocks_per_cu[key] <= 0) {
         int nb = 0;
         HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST>, RT_BLOCK, lds));
@@ -522,6 +525,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     std::vector<float4> rest;
     std::vector<int> slot_mesh, slot_rem, slot_id;
     std::vector<int> first_visit(n_nodes, -1);
+    std::vector<std::pair<int, int>> tlas_vnode_of_rec;
     const size_t visit_cap = 4 * (size_t)n_nodes + 16;
     int max_depth = 0;
     for (int j = 0; j < n_meshes; j++) {
@@ -579,6 +583,71 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
             }
         }
     }
+    // ---- more than 32 meshes: a top-level tree over the mesh roots replaces the flat mesh loop ----
+    // Its interior nodes are ordinary 64-byte records whose leaf children ARE the mesh roots
+    // (same box, same reference), so the traversal needs nothing new; their boxes are refit with
+    // the rest (levels above the mesh levels).  Exactness: a top-level box is the exact union of
+    // root boxes, so skipping it is the same conservative shortcut as skipping a missed root box.
+    int tlas_root = -1, tlas_height = 0;
+    if (n_meshes > 32) {
+        std::vector<float> cen(3 * (size_t)n_meshes, 0.f);
+        {
+            std::vector<float> lo(3 * (size_t)n_meshes, INFINITY), hi(3 * (size_t)n_meshes, -INFINITY);
+            for (int i = 0; i < n_tris; i++) {
+                const float* p[3] = {tris[i].posA, tris[i].posB, tris[i].posC};
+                const int j = tris[i].meshIndex;
+                for (int q = 0; q < 3; q++)
+                    for (int a = 0; a < 3; a++) {
+                        lo[3 * j + a] = std::min(lo[3 * j + a], p[q][a]);
+                        hi[3 * j + a] = std::max(hi[3 * j + a], p[q][a]);
+                    }
+            }
+            for (size_t k = 0; k < cen.size(); k++) cen[k] = std::isfinite(lo[k]) && std::isfinite(hi[k]) ? 0.5f * (lo[k] + hi[k]) : 0.f;
+        }
+        struct Job { std::vector<int> meshes; int depth, parent_rec, which; };
+        std::vector<Job> jobs;
+        std::vector<int> all(n_meshes);
+        for (int j = 0; j < n_meshes; j++) all[j] = j;
+        jobs.push_back({all, 0, -1, 0});
+        const int mesh_depth = max_depth;
+        while (!jobs.empty()) {
+            Job job = std::move(jobs.back());
+            jobs.pop_back();
+            int v, ref;
+            if (job.meshes.size() == 1) {                    // a mesh root: nothing new, just link it
+                v = root_v[job.meshes[0]];
+                ref = root_ref[job.meshes[0]];
+            } else {
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (int j : job.meshes)
+                    for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], cen[3 * j + a]); hi[a] = std::max(hi[a], cen[3 * j + a]); }
+                int axis = 0;
+                for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+                std::sort(job.meshes.begin(), job.meshes.end(), [&](int x, int y) {
+                    return cen[3 * x + axis] < cen[3 * y + axis] || (cen[3 * x + axis] == cen[3 * y + axis] && x < y);
+                });
+                const size_t half = job.meshes.size() / 2;
+                v = (int)vnodes.size();
+                vnodes.push_back({-1, -1, 0, 0});
+                vdepth.push_back(job.depth);
+                ref = (int)pack.size();
+                pack.push_back({-1, -1, RT_NONE, RT_NONE});
+                tlas_height = std::max(tlas_height, job.depth + 1);
+                jobs.push_back({std::vector<int>(job.meshes.begin(), job.meshes.begin() + half), job.depth + 1, ref, 1});
+                jobs.push_back({std::vector<int>(job.meshes.begin() + half, job.meshes.end()), job.depth + 1, ref, 2});
+                // remember which visit node this record belongs to (for vnode.c1/c2 below)
+                tlas_vnode_of_rec.push_back({ref, v});
+            }
+            if (job.parent_rec < 0) tlas_root = ref;
+            else if (job.which == 1) { pack[job.parent_rec].c1 = v; pack[job.parent_rec].ref1 = ref; }
+            else { pack[job.parent_rec].c2 = v; pack[job.parent_rec].ref2 = ref; }
+        }
+        for (auto& rv : tlas_vnode_of_rec) { vnodes[rv.second].c1 = pack[rv.first].c1; vnodes[rv.second].c2 = pack[rv.first].c2; }
+        // mesh levels move below the top-level ones: a parent is always refit after its children
+        const size_t n_mesh_visits = vnodes.size() - tlas_vnode_of_rec.size();
+        for (size_t v = 0; v < n_mesh_visits; v++) vdepth[v] += tlas_height;
+        max_depth = mesh_depth + tlas_height;
+    }
     // level lists (deepest first at refit time)
     std::vector<int> level_off(max_depth + 2, 0), level_nodes(vnodes.size());
     for (int d : vdepth) level_off[d + 1]++;
@@ -620,6 +689,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     c->h_dirty.assign((size_t)std::max(n_meshes, 1), 2);        // 2 = copy rest pose as given
     c->level_off = level_off;
     c->stack_depth = max_depth + 1;
+    c->tlas_root = tlas_root;
     c->node_first_visit = first_visit;
     c->h_nodes.assign(nodes, nodes + n_nodes);
     c->have_scene = true;
