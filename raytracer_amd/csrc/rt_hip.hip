@@ -252,6 +252,7 @@ struct rt_ctx {
     MatDev atmo{};
     int n_tris = 0, n_slots = 0, n_meshes = 0, n_nodes = 0, n_visit = 0, n_rec = 0, n_spheres = 0;
     int stack_depth = 1;
+    int tlas_above = 32;                  // scenes with more meshes than this get the top-level tree (the LDS root mask holds 32)
     int tlas_root = -1;                   // record of the top-level tree's root (scenes with > 32 meshes), else -1
     bool have_scene = false, have_cam = false, prep_pending = false;
     bool flags_pending = false;           // materials changed since the triangle flag words were written
@@ -445,6 +446,7 @@ int rt_create(int device, rt_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
     c->stream = c->own_stream;
+    if (const char* e = getenv("RT_TLAS_ABOVE")) c->tlas_above = std::max(1, std::min(32, atoi(e)));
     if (const char* e = getenv("RT_NODE_BIAS")) c->node_bias = atoi(e);
     if (const char* e = getenv("RT_BURST8")) c->burst8 = std::max(0, std::min(64, atoi(e)));
     if (const char* e = getenv("RT_REFILL_BELOW")) c->refill_below = std::max(1, std::min(64, atoi(e)));
@@ -589,7 +591,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     // the rest (levels above the mesh levels).  Exactness: a top-level box is the exact union of
     // root boxes, so skipping it is the same conservative shortcut as skipping a missed root box.
     int tlas_root = -1, tlas_height = 0;
-    if (n_meshes > 32) {
+    if (n_meshes > c->tlas_above) {
         std::vector<float> cen(3 * (size_t)n_meshes, 0.f);
         {
             std::vector<float> lo(3 * (size_t)n_meshes, INFINITY), hi(3 * (size_t)n_meshes, -INFINITY);
