@@ -1,0 +1,132 @@
+"""Seeded random scenes (triangle soups, boxes, tessellated spheres, analytic spheres; random
+materials incl. alpha, transmission, mirrors, emitters; 3 - 60 meshes so that both the LDS root
+mask and the top-level tree are taken; random cameras with depth of field) and the
+axis-aligned-ray corner of the slab test: HIP STRICT == oracle bit for bit, HIP CULL == HIP
+STRICT."""
+import numpy as np
+import pytest
+
+from conftest import make_ctx
+from raytracer_amd.scripts.classes import Material, Scene, Sphere
+from raytracer_amd.scripts.numba_utils.classes import Csys
+from raytracer_amd.scripts.scenes import chunker
+from raytracer_amd.scripts.scenes.utils import reset_global_datas
+from raytracer_amd.vecmath import Vector3, Vector4
+from synth import add_mesh, box_triangles, uv_sphere
+
+F = np.float32
+
+
+def _material(r):
+    kind = r.integers(0, 6)
+    col = Vector4((*r.uniform(0.1, 1.0, 3), 1.0), dtype="f4")
+    if kind == 0:
+        return Material(Vector4((0, 0, 0, 1.0), dtype="f4"), emissionColor=Vector3(r.uniform(0.5, 1, 3), dtype="f4"),
+                        emissionStrength=float(r.uniform(1, 8)))
+    if kind == 1:
+        return Material(col, smoothness=float(r.uniform(0.8, 1)), specularStrength=1.0)                  # mirror
+    if kind == 2:
+        return Material(col, smoothness=1.0, specularStrength=float(r.uniform(0, 0.2)), transmission=float(r.uniform(0.5, 1)),
+                        ior=float(r.uniform(1.1, 1.8)), specularColor=Vector3(r.uniform(0.5, 1, 3), dtype="f4"))   # glass
+    if kind == 3:
+        col = Vector4((*r.uniform(0.1, 1.0, 3), float(r.uniform(0.1, 0.9))), dtype="f4")
+        return Material(col, transparent_from_behind=bool(r.integers(0, 2)))                           # alpha veil
+    return Material(col, smoothness=float(r.uniform(0, 1)), specularStrength=float(r.uniform(0, 0.7)), metallic=float(r.uniform(0, 1)))
+
+
+def random_scene(seed):
+    reset_global_datas()
+    r = np.random.default_rng(seed)
+    sc = Scene()
+    sc.atmosphere_material = Material(Vector4((*r.uniform(0.7, 1, 3), 1.0), dtype="f4"), transmission=float(r.uniform(0.9, 1)), ior=1.0)
+    n_meshes = int(r.choice([3, 9, 31, 32, 33, 60]))
+    add_mesh(sc, *box_triangles((-8, -2.2, -8), (8, -2, 8)), _material(r))                              # something to land on
+    for _ in range(n_meshes - 1):
+        c = Csys()
+        c.set_pos(r.uniform((-4, -1.5, -3), (4, 3, 5)))
+        c.rxg(float(r.uniform(0, 360))).ryg(float(r.uniform(0, 360))).rzg(float(r.uniform(0, 360)))
+        shape = r.integers(0, 3)
+        if shape == 0:
+            h = r.uniform(0.1, 0.8, 3)
+            pos, nrm = box_triangles(-h, h)
+        elif shape == 1:
+            pos, nrm = uv_sphere((0, 0, 0), float(r.uniform(0.2, 0.9)), int(r.integers(5, 12)), int(r.integers(3, 8)))
+        else:                                                                                         # soup incl. slivers
+            n = int(r.integers(1, 40))
+            ctr = r.uniform(-0.5, 0.5, (n, 1, 3))
+            pos = (ctr + r.normal(0, 0.25, (n, 3, 3)) * r.choice([1.0, 1e-3], (n, 1, 1))).astype(F)
+            nrm = r.normal(0, 1, (n, 3, 3)).astype(F)
+        add_mesh(sc, pos, nrm, _material(r), c)
+    chunker.BVHGraph.register_all_and_update_node_tri_ids()
+    for _ in range(int(r.integers(0, 4))):
+        sc.spheres.append(Sphere(Vector3(r.uniform((-4, -1, -2), (4, 3, 5))), float(r.uniform(0.2, 1.0)), _material(r)))
+    cam = sc.cam
+    cam.csys.set_pos(r.uniform((-2, 0, -10), (2, 3, -7)))
+    cam.csys.ryg(float(r.uniform(-10, 10))).rxg(float(r.uniform(-10, 5)))
+    cam.fov = float(r.uniform(25, 60))
+    cam.near_plane = float(r.uniform(5, 10))
+    cam.depth_of_field_strength = float(r.choice([0.0, 0.01, 0.05]))
+    cam.antialias_strength = float(r.choice([0.0, 0.002]))
+    return sc
+
+
+def _render(lib, sc, w, h, cull, passes, rpp, bounces):
+    c = make_ctx(lib, sc, w, h)
+    c.set_cull(cull)
+    c.enable_stats(True)
+    ids, ts = c.first_hit(1)
+    c.render(1, passes, 1, rpp, bounces, 0)
+    return ids, ts, c.read_mean(), c.stats()
+
+
+def test_random_scene_is_renderable_by_the_oracle(oracle_lib):
+    ids, ts, img, st = _render(oracle_lib, random_scene(5), 48, 27, False, 1, 1, 3)
+    assert np.isfinite(img).all() and (ids >= 0).any() and st["rays"] > 48 * 27
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(1, 25)))
+def test_random_scenes_bit_exact(oracle_lib, hip_lib, seed):
+    w, h, passes, rpp, bounces = 96, 54, 2, 2, 6
+    io, to, a, so = _render(oracle_lib, random_scene(seed), w, h, False, passes, rpp, bounces)
+    ig, tg, b, sg = _render(hip_lib, random_scene(seed), w, h, False, passes, rpp, bounces)
+    assert np.array_equal(io, ig), f"seed {seed}: {(io != ig).sum()} first-hit ids differ"
+    assert np.array_equal(to.view(np.uint32), tg.view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"seed {seed}: {(a != b).any(axis=2).sum()} pixels differ"
+    assert so["rays"] == sg["rays"] and so["tri_tests"] == sg["tri_tests"] and so["shaded_hits"] == sg["shaded_hits"]
+    ic, tc, c, _ = _render(hip_lib, random_scene(seed), w, h, True, passes, rpp, bounces)
+    assert np.array_equal(ig, ic) and np.array_equal(tg.view(np.uint32), tc.view(np.uint32))
+    assert np.array_equal(b.view(np.uint32), c.view(np.uint32)), f"seed {seed}: CULL differs from STRICT in {(b != c).any(axis=2).sum()} pixels"
+
+
+def _axis_scene():
+    """Identity camera at the origin, odd image size, no jitter: the centre pixel's ray is exactly
+    (0, 0, 1) -> 1/d = inf on two axes; boxes with faces in the planes x = 0 and y = 0 make
+    (b - o) * (1/d) = 0 * inf = NaN.  The reference's compare ladder decides those cases."""
+    reset_global_datas()
+    sc = Scene()
+    sc.atmosphere_material = Material(Vector4((1, 1, 1, 1.0), dtype="f4"), transmission=1.0, ior=1.0)
+    grey = Material(Vector4((0.7, 0.7, 0.7, 1.0), dtype="f4"))
+    light = Material(Vector4((0, 0, 0, 1.0), dtype="f4"), emissionColor=Vector3((1, 1, 1), dtype="f4"), emissionStrength=3.0)
+    add_mesh(sc, *box_triangles((0, 0, 4), (1, 1, 5)), grey)          # corner on the axis: faces x = 0 and y = 0
+    add_mesh(sc, *box_triangles((-1, -1, 6), (0, 0, 7)), grey)        # the opposite corner
+    add_mesh(sc, *box_triangles((-3, -3, 9), (3, 3, 9.5)), light)     # back wall, emits
+    add_mesh(sc, *uv_sphere((0, 0, 2.0), 0.3, 8, 4), Material(Vector4((1, 1, 1, 0.3), dtype="f4")))   # pole on the axis, mostly see-through
+    chunker.BVHGraph.register_all_and_update_node_tri_ids()
+    sc.cam.fov = 50
+    sc.cam.near_plane = 1.0
+    sc.cam.antialias_strength = 0.0
+    sc.cam.depth_of_field_strength = 0.0
+    return sc
+
+
+@pytest.mark.gpu
+def test_axis_aligned_rays_and_nan_slabs(oracle_lib, hip_lib):
+    w, h = 65, 37
+    io, to, a, so = _render(oracle_lib, _axis_scene(), w, h, False, 3, 1, 4)
+    ig, tg, b, sg = _render(hip_lib, _axis_scene(), w, h, False, 3, 1, 4)
+    assert np.array_equal(io, ig) and np.array_equal(to.view(np.uint32), tg.view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert so["rays"] == sg["rays"] and so["tri_tests"] == sg["tri_tests"]
+    ic, tc, c, _ = _render(hip_lib, _axis_scene(), w, h, True, 3, 1, 4)
+    assert np.array_equal(ig, ic) and np.array_equal(b.view(np.uint32), c.view(np.uint32))
