@@ -141,14 +141,13 @@ __device__ __forceinline__ bool culled(float tmin, float tmax, float best_t) {
     return (tmax < RT_CULL_BEHIND) || (tmin > fma_(best_t, RT_CULL_REL, best_t) + RT_CULL_ABS);
 }
 
-// Entry distance of a deferred child, kept in 16 bits (LDS is what limits occupancy here):
-// the top half of the binary32 pattern, rounded DOWN so that the re-check at pop can only
-// cull less than the full value would.  NaN stays NaN (never culls).
-__device__ __forceinline__ unsigned short pack_dist(float t) {
-    uint32_t u = __float_as_uint(t);
-    if ((u >> 31) && (u & 0xffffu) && (u & 0x7f800000u) != 0x7f800000u) u += 0x10000u;   // negative: larger magnitude
-    return (unsigned short)(u >> 16);
-}
+// Entry distance of a deferred child, kept in 16 bits (LDS is what limits occupancy here): the
+// top half of the binary32 pattern.  Truncation rounds a positive distance down, so the re-check
+// when the child is taken up can only cull less than the full value would; a negative distance
+// (the origin is inside or past the box) moves towards zero but keeps its sign, and no
+// non-positive distance is ever beyond the best hit; a NaN produced by arithmetic has its quiet
+// bit (bit 22) set and stays NaN (never culls).
+__device__ __forceinline__ unsigned short pack_dist(float t) { return (unsigned short)(__float_as_uint(t) >> 16); }
 __device__ __forceinline__ float unpack_dist(unsigned short h) { return __uint_as_float((uint32_t)h << 16); }
 
 // fragPosition -> world-space view point (raytracer.fs.glsl:961-962, raytracer.vs.glsl:6-9)
