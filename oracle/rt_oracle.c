@@ -301,6 +301,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
         (n_spheres && !spheres96) || !atmosphere80)
         FAIL(c, RT_E_ARG, "null buffer with non-zero count");
     if (n_meshes > 256 || n_spheres > 256) FAIL(c, RT_E_LIMIT, "more than 256 meshes/spheres (shader arrays, :15-17)");
+    if (n_tris > (1 << 25) || n_nodes > (1 << 25)) FAIL(c, RT_E_LIMIT, "more than 2^25 triangles or nodes (the product's limit, mirrored)");
     free_scene(c);
     c->tris = (Triangle*)dup_mem(tris28, (size_t)n_tris * 112);
     c->tris0 = (Triangle*)dup_mem(tris28, (size_t)n_tris * 112);
@@ -425,7 +426,7 @@ int rt_set_camera(rt_ctx* c, const float vp[3], const float m[16], const float p
 
 int rt_resize(rt_ctx* c, int w, int h) {
     if (!c) return RT_E_ARG;
-    if (w <= 0 || h <= 0 || (int64_t)w * h > (1 << 28)) FAIL(c, RT_E_ARG, "bad image size %dx%d", w, h);
+    if (w <= 0 || h <= 0 || w > 32768 || h > 32768 || (int64_t)w * h > (1 << 28)) FAIL(c, RT_E_ARG, "bad image size %dx%d", w, h);
     float* p = (float*)calloc((size_t)w * h * 3, 4);
     if (!p) FAIL(c, RT_E_NOMEM, "accumulator allocation failed");
     if (c->accum == c->accum_own) c->accum = p;
@@ -737,6 +738,7 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
     if (!c) return RT_E_ARG;
     if (!ready(c)) return RT_E_STATE;
     if (rpp < 1 || maxBounces < 0 || stride < 1) FAIL(c, RT_E_ARG, "bad sampling arguments");
+    if (flags != RT_ACCUM_MEAN && flags != RT_ACCUM_SUM) FAIL(c, RT_E_ARG, "bad flags");
     if (flags == RT_ACCUM_MEAN && stride != 1) FAIL(c, RT_E_ARG, "running mean needs pass_stride 1");
     uint64_t rays = 0, box = 0, tri = 0, hits = 0;
     const int W = c->w, H = c->h;

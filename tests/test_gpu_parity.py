@@ -101,3 +101,10 @@ def test_animated_frame_parity(oracle_lib, hip_lib):
     o.render(1, 2, 1, 1, 4, 0)
     g.render(1, 2, 1, 1, 4, 0)
     assert np.array_equal(o.read_mean().view(np.uint32), g.read_mean().view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_error_codes_match_the_oracle(oracle_lib, hip_lib, suzanne):
+    from test_host_model import check_error_codes
+
+    assert check_error_codes(hip_lib, suzanne) == check_error_codes(oracle_lib, suzanne)
