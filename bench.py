@@ -219,7 +219,8 @@ def main() -> None:
 
 def cpu_baseline(passes: int) -> dict:
     """The CPU oracle (a port: the reference has no CPU renderer) on a bounded sample of the
-    same workload: same scene/camera/seeds, the first `passes` of the 64 passes."""
+    same workload: same scene/camera/seeds, the first `passes` of the 64 passes on all the
+    threads OpenMP gives us, and pass 1 alone on one thread."""
     from raytracer_amd import ffi
     from raytracer_amd.scripts.scenes import final_scene_numba as S
 
@@ -232,11 +233,20 @@ def cpu_baseline(passes: int) -> dict:
     ctx.load_scene(scene)
     ctx.load_camera(scene.cam)
     ctx.resize(WIDTH, HEIGHT)
-    ctx.reset_stats()
-    t0 = time.perf_counter()
-    ctx.render(1, passes, 1, RPP, BOUNCES, ffi.RT_ACCUM_MEAN)
-    dt = time.perf_counter() - t0
-    rays = ctx.stats()["rays"]
+
+    def timed(n_passes):
+        ctx.reset_stats()
+        ctx.reset_accum()
+        t0 = time.perf_counter()
+        ctx.render(1, n_passes, 1, RPP, BOUNCES, ffi.RT_ACCUM_MEAN)
+        dt = time.perf_counter() - t0
+        return ctx.stats()["rays"], dt
+
+    rays, dt = timed(passes)
+    lib.dll.rto_set_threads(1)
+    ctx.resize(WIDTH // 2, HEIGHT // 2)            # a quarter of the pixels keeps the scalar run to seconds
+    rays1, dt1 = timed(1)
+    lib.dll.rto_set_threads(threads)
     ctx.close()
     return {
         "value": round(rays / dt / 1e6, 3),
@@ -245,6 +255,8 @@ def cpu_baseline(passes: int) -> dict:
         "kind": "port",
         "sample": f"oracle/rt_oracle.c (OpenMP), same scene/camera/seeds, {WIDTH}x{HEIGHT}, passes 1..{passes} of {PASSES}, "
                   f"{BOUNCES} bounces: {rays} rays in {dt:.2f} s",
+        "single_thread": {"value": round(rays1 / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
+                          "sample": f"pass 1 at {WIDTH // 2}x{HEIGHT // 2}: {rays1} rays in {dt1:.2f} s"},
     }
 
 
