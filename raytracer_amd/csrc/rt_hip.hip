@@ -373,7 +373,7 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.n_chunks = 0;
     a.node_bias = c->node_bias;
     a.burst8 = c->burst8;
-    a.refill_below = c->refill_below > 0 ? c->refill_below : (c->cull ? 16 : 32);   // best measured, DESIGN.md 5
+    a.refill_below = c->refill_below > 0 ? c->refill_below : (c->cull ? 28 : 32);   // best measured, DESIGN.md 5
 }
 
 template <bool STATS, bool CULL, bool FIRST>
