@@ -1,6 +1,6 @@
 """Entry point with the reference's shape (run.py:1-10): pick a scene module, start the app.
 
-    python run.py [--frames N] [--height H] [--passes P] [--bounces B]
+    python run.py [--frames N] [--height H] [--passes P] [--bounces B] [--cull]
 
 Headless: renders N animation frames of the Suzanne scene on GPU 0 and writes PNG + float32
 dumps under renders/RayTracerDynamic/<timestamp>/ at the reference's cadence."""
@@ -14,6 +14,7 @@ if __name__ == "__main__":
     ap.add_argument("--height", type=int, default=1080 // 4)
     ap.add_argument("--passes", type=int, default=None, help="override the scene's passes_per_frame")
     ap.add_argument("--bounces", type=int, default=None)
+    ap.add_argument("--cull", action="store_true", help="distance culling (same image, fewer box tests)")
     args = ap.parse_args()
 
     from raytracer_amd.scripts.animate import FrameAnimation
@@ -28,5 +29,14 @@ if __name__ == "__main__":
             if args.bounces is not None:
                 cam.bounces_per_ray = args.bounces
         final_scene_numba.scene.animations.append(FrameAnimation(final_scene_numba.scene.cam, override))
+    prog = None
+    if args.cull:
+        app0 = application.Application.__new__(application.Application)
+        prog = application.RayTracerDynamic(app=app0, file_vertex_shader="shaders/raytracer.vs.glsl",
+                                            file_fragment_shader="shaders/raytracer.fs.glsl",
+                                            width=args.height * 16 // 9, height=args.height, cull=True)
+        application.Application.__init__(app0, render_height=args.height, max_frames=args.frames, program=prog)
+        app0.start()
+        raise SystemExit(0)
     app = application.Application(render_height=args.height, max_frames=args.frames)
     app.start()

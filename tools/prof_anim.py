@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2]: the keyframe animation of the Suzanne room through the Application /
+RayTracerDynamic mirror - per frame: animate hooks (host), pose + material + camera updates over
+the C-ABI, device pose/refit, 64 passes at 1080p, read-back of the mean.  Prints s/frame.
+usage: python tools/prof_anim.py [frames] [height] [passes] [bounces]"""
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import raytracer_amd.scripts.application as A
+from raytracer_amd.scripts.animate import FrameAnimation
+from raytracer_amd.scripts.scenes import final_scene_numba as S
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+height = int(sys.argv[2]) if len(sys.argv) > 2 else 1080
+passes = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+bounces = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+
+
+def override(cam, i):
+    cam.passes_per_frame = passes
+    cam.bounces_per_ray = bounces
+
+
+S.scene.animations.append(FrameAnimation(S.scene.cam, override))
+A.set_scene(S)
+A.HEADLESS = True
+app = A.Application.__new__(A.Application)
+prog = A.RayTracerDynamic.__new__(A.RayTracerDynamic)
+A.RayTracerDynamic.__init__(prog, app, file_vertex_shader="shaders/raytracer.vs.glsl", file_fragment_shader="shaders/raytracer.fs.glsl",
+                            width=height * 16 // 9, height=height, save_frames=False, cull=True)
+A.Application.__init__(app, render_height=height, max_frames=frames + 1, program=prog)
+t = []
+orig = prog.calculate_frame
+
+
+def timed(scene):
+    t0 = time.perf_counter()
+    orig(scene)
+    t.append(time.perf_counter() - t0)
+
+
+prog.calculate_frame = timed
+app.start()
+steady = t[1:]                                  # the first frame carries start-up costs
+print(f"{len(steady)} frames {prog.width}x{prog.height}, {passes} passes, {bounces} bounces: "
+      f"{sum(steady) / len(steady) * 1e3:.1f} ms per frame ({len(steady) / sum(steady):.2f} frames/s), first frame {t[0] * 1e3:.1f} ms")
