@@ -225,18 +225,21 @@ struct Trav {
 template <bool STATS, bool CULL, bool FINITE>
 __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn, v3 org, v3 inv, float best_t, Counters& cnt) {
     uint32_t mask = 0;
-    // two boxes per trip: their four LDS reads are in flight together (one exposed LDS latency
-    // per trip instead of one per mesh); the tail re-reads the last box and masks its bit off
-    for (int b0 = 0; b0 < jn; b0 += 2) {
-        float4 lo[2], hi[2];
+    // One box per trip, not unrolled: the kernel is issue bound, so overlapping the LDS latency
+    // of several boxes buys nothing, while two or three boxes in flight cost spilled registers
+    // (0.8 GB of scratch writes per frame, measured).
+    constexpr int NB = 1;
+#pragma nounroll
+    for (int b0 = 0; b0 < jn; b0 += NB) {
+        float4 lo[NB], hi[NB];
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < NB; u++) {
             const int j = min(b0 + u, jn - 1);
             lo[u] = s_roots[2 * j];
             hi[u] = s_roots[2 * j + 1];
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+        for (int u = 0; u < NB; u++) {
             float ta, tb;
             const bool h = FINITE ? box_test_finite(org, inv, lo[u], hi[u], ta, tb) : box_test(org, inv, lo[u], hi[u], ta, tb);
             const bool real = __float_as_int(lo[u].w) != RT_NONE && b0 + u < jn;
@@ -308,7 +311,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     int prev_id = -1, prev_mat = -1, bounce = 0;
     float ior = 1.0f;
     bool in_solid = false;
-    int hb_key = 0, hb_msk = RT_TFB_BIT;   // hitBehind test of the ray in flight (set at query start)
+    int hb_key = 0;            // hitBehind test of the ray in flight: the mesh it is inside, or 0 (set at query start)
     Trav tv;
     tv.cur = RT_NONE; tv.sp = 0; tv.lq = 0; tv.k = -1; tv.mask = 0; tv.node_live = false;
     tv.best_t = 1e20f; tv.best_rank = RT_MISS_RANK;
@@ -418,7 +421,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             if (STATS) cnt.tri += tested;
                             // hitBehind for this triangle's mesh (:605-615; in a solid: same mesh only [9.6])
                             // = in_solid ? mesh == prev_mesh : !transparentFromBehind, through the per-ray key/mask
-                            const bool hb = ((__float_as_int(g3.w) ^ hb_key) & hb_msk) == 0;
+                            const bool hb = ((__float_as_int(g3.w) ^ hb_key) & (in_solid ? ~RT_TFB_BIT : RT_TFB_BIT)) == 0;
                             const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
                             const v3 N = V3(g0.w, g1.w, g2.w);
                             const float nd = dot3(N, dir);
@@ -638,7 +641,6 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 // in a solid only the mesh the ray is inside shows its back faces (prev_mat = -1 or a
                 // sphere never equals a mesh index); outside, every mesh that is not transparentFromBehind
                 hb_key = in_solid ? prev_mat : 0;
-                hb_msk = in_solid ? ~RT_TFB_BIT : RT_TFB_BIT;
                 const int n_sph = __builtin_amdgcn_readfirstlane(PS.n_spheres);
                 for (int i = 0; i < n_sph; i++) {
                     const SphereDev& sph = PS.spheres[i];
