@@ -7,12 +7,18 @@
 //   k_refit_level device twin of the chunker refit (scripts/scenes/chunker.py:197-214),
 //                 bottom-up by tree level (exact: min/max are associative)
 //   k_pack_nodes  copies refreshed child boxes into the 64-byte traversal records
-//   k_trace       ray generation + traversal + bounce loop + accumulation
-//                 (shaders/raytracer.fs.glsl main() :928-1044), wave-scheduled state machine;
-//                 FIRST_HIT instantiation = primary-ray closest hit only (parity probe)
+//   k_tri_flags   refreshes the per-triangle flag word after rt_set_materials
+//   k_trace       ray generation + traversal + bounce loop (shaders/raytracer.fs.glsl main()
+//                 :928-1007 and everything it calls): persistent waves, wave-voted node /
+//                 triangle / path steps (rt_dev_trace.h); writes one radiance value per
+//                 (pass, pixel); FIRST_HIT instantiation = primary-ray closest hit only
+//   k_accumulate  running mean / sum over the passes of a launch (:1008-1042), in pass order
 //   k_gather_*    read-back of posed triangles / refit boxes in the reference's std140 order
+// Host: scene upload (traversal-order slots, 64-byte node records, top-level tree for scenes with
+// more than 32 meshes), batched pose/refit, launch logic.  rt_bvh.cpp holds the BVH builder.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see __graft_entry__.py).
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DRT_WAVES=6
+// (see __graft_entry__.py).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1,6 +1,6 @@
 """Synthetic scenes that exercise the branches the Suzanne room never takes: spheres, glass
 (transmission / inSolid / ior bookkeeping), alpha pass-through, specular mix, > 32 meshes
-(second group of mesh roots), depth of field, empty space (misses)."""
+(top-level tree over the mesh roots), depth of field, empty space (misses)."""
 import numpy as np
 
 from raytracer_amd.scripts.classes import Material, Mesh, Scene, Sphere
@@ -76,7 +76,7 @@ def stress_scene(n_cubes=40, spheres=True, dof=0.02):
     # glass ball (mesh) and a veil in front of the camera
     add_mesh(sc, *uv_sphere((0.0, 0.3, 0.0), 1.2, 14, 9), glass)
     add_mesh(sc, *box_triangles((-1.5, -1, -3.0), (1.5, 2, -2.95)), veil)
-    # many small posed cubes: more than 32 meshes -> second group of mesh roots
+    # many small posed cubes: more than 32 meshes -> the top-level tree instead of the LDS root mask
     for i in range(n_cubes):
         from raytracer_amd.scripts.numba_utils.classes import Csys
 
