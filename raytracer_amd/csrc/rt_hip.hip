@@ -421,6 +421,22 @@ int check_ready(rt_ctx* c) {
     return RT_OK;
 }
 
+// Fold the event pairs whose launches have already finished into kernel_ms without blocking, so
+// that a long render loop which never asks for statistics does not pile up events.
+void note_launch(rt_ctx* c, hipEvent_t e0, hipEvent_t e1) {
+    c->pending_events.push_back({e0, e1});
+    if (c->pending_events.size() < 64) return;
+    size_t done = 0;
+    while (done < c->pending_events.size() && hipEventQuery(c->pending_events[done].second) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->pending_events[done].first, c->pending_events[done].second) == hipSuccess) c->st.kernel_ms += ms;
+        (void)hipEventDestroy(c->pending_events[done].first);
+        (void)hipEventDestroy(c->pending_events[done].second);
+        done++;
+    }
+    c->pending_events.erase(c->pending_events.begin(), c->pending_events.begin() + done);
+}
+
 int resolve_events(rt_ctx* c) {
     if (c->pending_events.empty()) return RT_OK;
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -876,7 +892,7 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
         HIPCK(c, hipEventRecord(e0, c->stream));
         if ((rc = launch_trace(c, a, false))) return rc;
         HIPCK(c, hipEventRecord(e1, c->stream));
-        c->pending_events.push_back({e0, e1});
+        note_launch(c, e0, e1);
         c->st.launches++;
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, c->stream, c->totals.p, c->accum,
                            (size_t)n_px, a.first_pass, a.n_passes, stride, rpp, a.sum_mode);
@@ -917,7 +933,7 @@ int rt_first_hit(rt_ctx* c, uint32_t pass, int32_t* ids, float* ts) {
     rc = launch_trace(c, a, true);
     if (rc) { d_ids.release(); d_ts.release(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     (void)hipEventRecord(e1, c->stream);
-    c->pending_events.push_back({e0, e1});
+    note_launch(c, e0, e1);
     c->st.launches++;
     c->st.samples += n;
     hipError_t e = hipGetLastError();

@@ -108,3 +108,18 @@ def test_error_codes_match_the_oracle(oracle_lib, hip_lib, suzanne):
     from test_host_model import check_error_codes
 
     assert check_error_codes(hip_lib, suzanne) == check_error_codes(oracle_lib, suzanne)
+
+
+@pytest.mark.gpu
+def test_many_launches_keep_their_timing(hip_lib, suzanne):
+    """A long loop of small renders without a statistics call in between: every launch is timed
+    and the event list stays bounded (finished pairs are folded in as the loop goes)."""
+    c = make_ctx(hip_lib, suzanne, 64, 36)
+    c.reset_stats()
+    for p in range(300):
+        c.render(p + 1, 1, 1, 1, 2, 0)
+    st = c.stats()
+    assert st["launches"] == 300 and st["kernel_ms"] > 0
+    ref = make_ctx(hip_lib, build_suzanne(), 64, 36)
+    ref.render(1, 300, 1, 1, 2, 0)
+    assert np.array_equal(c.read_mean().view(np.uint32), ref.read_mean().view(np.uint32))   # segmented == one call
