@@ -160,6 +160,22 @@ def main() -> None:
 
     value = rays_step * args.steps / dt / 1e6
 
+    # for the record: the same frame with the reference's exact box set (no distance culling);
+    # not the headline (the culled traversal renders the identical image, tests/test_gpu_fullsize.py)
+    strict = None
+    if world == 1 and not args.strict:
+        ctx.set_cull(False)
+        step()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(dev)
+        dts = (time.perf_counter() - t1) / 2
+        strict = {"ms_per_step": round(dts * 1e3, 3), "value": round(rays_step / dts / 1e6, 2), "unit": "Mrays/s",
+                  "note": "reference's exact box set (rt_set_cull(0)), same rays"}
+        ctx.set_cull(True)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.cpu_passes)
@@ -210,6 +226,7 @@ def main() -> None:
                                   "the scene is 130 KB"},
             },
             "cpu_baseline": cpu,
+            "strict_traversal": strict,
         }
         print(json.dumps(out), flush=True)
     ctx.close()
