@@ -118,6 +118,17 @@ int rt_bvh_build(const float* pos9, int n_tris, int32_t first_node_id, int32_t f
 int rt_bvh_refit(const float* pos9, int n_tris, int32_t first_tri_id, int32_t first_leaf_offset,
                  void* nodes48, int n_nodes, const int32_t* leaf_tri_ids);
 
+/* NO counterpart in the reference: which per-mesh tree the NEXT rt_set_scene builds on the device.
+ * RT_ACCEL_REFERENCE (default): the uploaded nodes, i.e. the reference's own BVH - the parity
+ * structure, results identical to the reference's traversal.  RT_ACCEL_SAH: a binned-SAH tree with
+ * leaves of <= 4 triangles over the same triangles ("performance
+ * structure"); equal-distance hits still resolve in the reference's order, but other boxes are
+ * tested, so a hit can differ where the reference's leaf box misses a triangle by rounding.
+ * rt_read_nodes48 is unavailable for such a scene.  Oracle: accepted and ignored. */
+#define RT_ACCEL_REFERENCE 0
+#define RT_ACCEL_SAH 1
+int rt_set_accel(rt_ctx* ctx, int accel);
+
 /* replaces: the camera uniform writes of calculate_frame (application.py:1175-1180):
  * ViewParams, CamLocalToWorldMatrix (numpy row-major float32 bytes), CamGlobalPos,
  * depthOfFieldStrength, antialiasStrength */

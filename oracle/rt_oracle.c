@@ -830,6 +830,7 @@ int rt_reset_stats(rt_ctx* c) { if (!c) return RT_E_ARG; memset(&c->st, 0, sizeo
 int rt_get_stats(rt_ctx* c, rt_stats_t* o) { if (!c || !o) return RT_E_ARG; *o = c->st; return RT_OK; }
 int rt_sync(rt_ctx* c) { return c ? RT_OK : RT_E_ARG; }
 int rt_set_cull(rt_ctx* c, int e) { (void)e; return c ? RT_OK : RT_E_ARG; } /* the oracle never culls */
+int rt_set_accel(rt_ctx* c, int accel) { (void)accel; return c ? RT_OK : RT_E_ARG; }   /* one structure only: the reference's */
 int rt_set_stream(rt_ctx* c, void* s) { (void)s; return c ? RT_OK : RT_E_ARG; }
 void* rt_stream(rt_ctx* c) { (void)c; return NULL; }
 

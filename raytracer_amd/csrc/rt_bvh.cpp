@@ -180,3 +180,120 @@ int rt_bvh_refit(const float* pos9, int n_tris, int32_t first_tri_id, int32_t fi
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Binned SAH builder for the opt-in performance structure (rt_set_accel(RT_ACCEL_SAH)).  Not a
+// restatement of anything in the reference: its BVH (above) costs 12 triangle tests per ray on
+// the benchmark scene because a 12-triangle wall slab ends up as two leaves that both span the
+// whole slab.  Topology only: boxes are refit on the device from the posed triangles.
+// ---------------------------------------------------------------------------------------------
+#include <algorithm>
+
+#include "rt_bvh_internal.h"
+
+namespace {
+
+struct SahPrim { float lo[3], hi[3], c[3]; int32_t id; };
+struct SahBox {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    void grow(const float* l, const float* h) {
+        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); }
+    }
+    float half_area() const {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return (dx < 0 || dy < 0 || dz < 0) ? 0.f : dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct SahBuilder {
+    std::vector<SahPrim> prims;
+    std::vector<RtNode48>* nodes;
+    std::vector<int32_t>* leaf_ids;
+    int max_depth;
+
+    int build(int b, int e, int depth) {
+        const int ni = (int)nodes->size();
+        RtNode48 nd;
+        std::memset(&nd, 0, sizeof(nd));
+        SahBox box, cbox;
+        for (int i = b; i < e; i++) { box.grow(prims[i].lo, prims[i].hi); cbox.grow(prims[i].c, prims[i].c); }
+        for (int a = 0; a < 3; a++) { nd.lo[a] = box.lo[a]; nd.hi[a] = box.hi[a]; }
+        nd.id = ni; nd.c1 = nd.c2 = -1; nd.off = -1; nd.cnt = e - b;
+        nodes->push_back(nd);
+        const int n = e - b;
+        if (n <= 4 || depth >= max_depth) return make_leaf(ni, b, e);
+        // best of 3 axes x 15 bin boundaries
+        constexpr int NB = 16;
+        float best_cost = INFINITY;
+        int best_axis = -1, best_split = 0;
+        for (int a = 0; a < 3; a++) {
+            const float ext = cbox.hi[a] - cbox.lo[a];
+            if (!(ext > 0.f)) continue;
+            SahBox bb[NB];
+            int cnt[NB] = {0};
+            const float scale = NB / ext;
+            for (int i = b; i < e; i++) {
+                int k = std::min(NB - 1, std::max(0, (int)((prims[i].c[a] - cbox.lo[a]) * scale)));
+                cnt[k]++;
+                bb[k].grow(prims[i].lo, prims[i].hi);
+            }
+            float right_area[NB];
+            int right_cnt[NB];
+            SahBox acc;
+            int c = 0;
+            for (int k = NB - 1; k > 0; k--) { acc.grow(bb[k].lo, bb[k].hi); c += cnt[k]; right_area[k] = acc.half_area(); right_cnt[k] = c; }
+            SahBox left;
+            int lc = 0;
+            for (int k = 0; k < NB - 1; k++) {
+                left.grow(bb[k].lo, bb[k].hi);
+                lc += cnt[k];
+                if (lc == 0 || right_cnt[k + 1] == 0) continue;
+                const float cost = left.half_area() * lc + right_area[k + 1] * right_cnt[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
+            }
+        }
+        int mid;
+        if (best_axis < 0) {                               // all centroids coincide: split by count
+            mid = b + n / 2;
+        } else {
+            const float ext = cbox.hi[best_axis] - cbox.lo[best_axis], scale = NB / ext, lo0 = cbox.lo[best_axis];
+            const int a = best_axis, s = best_split;
+            mid = (int)(std::partition(prims.begin() + b, prims.begin() + e, [&](const SahPrim& p) {
+                      return std::min(NB - 1, std::max(0, (int)((p.c[a] - lo0) * scale))) <= s;
+                  }) - prims.begin());
+            if (mid == b || mid == e) mid = b + n / 2;
+        }
+        const int l = build(b, mid, depth + 1);
+        const int r = build(mid, e, depth + 1);
+        (*nodes)[ni].c1 = l;
+        (*nodes)[ni].c2 = r;
+        return ni;
+    }
+    int make_leaf(int ni, int b, int e) {
+        (*nodes)[ni].off = (int32_t)leaf_ids->size();
+        for (int i = b; i < e; i++) leaf_ids->push_back(prims[i].id);
+        return ni;
+    }
+};
+
+}  // namespace
+
+int rt_sah_build(const float* pos9, const int32_t* tri_ids, int n, int max_depth, std::vector<RtNode48>& nodes,
+                 std::vector<int32_t>& leaf_ids) {
+    SahBuilder sb;
+    sb.nodes = &nodes;
+    sb.leaf_ids = &leaf_ids;
+    sb.max_depth = max_depth;
+    sb.prims.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        SahPrim& p = sb.prims[i];
+        const float* q = pos9 + 9 * (size_t)i;
+        for (int a = 0; a < 3; a++) {
+            p.lo[a] = std::min(q[a], std::min(q[3 + a], q[6 + a]));
+            p.hi[a] = std::max(q[a], std::max(q[3 + a], q[6 + a]));
+            p.c[a] = 0.5f * (p.lo[a] + p.hi[a]);
+        }
+        p.id = tri_ids[i];
+    }
+    return sb.build(0, n, 0);
+}

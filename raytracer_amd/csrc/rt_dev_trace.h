@@ -12,12 +12,14 @@
 //
 // Data layout in HBM (built by rt_set_scene, refreshed by the prep kernels):
 //   tri_geo  4 x float4 per triangle SLOT (64 B, one half cache line):
-//              {A.xyz, N.x} {B.xyz, N.y} {C.xyz, N.z} {d, bits(rem), bits(triId), bits(flags)}
+//              {A.xyz, N.x} {B.xyz, N.y} {C.xyz, N.z} {d, bits(rem), bits(rank), bits(flags)}
 //            slots are in traversal order of the reference (mesh ascending, depth-first,
 //            second child first, leaf order), so (a) every leaf and every subtree is one
 //            contiguous range, (b) the slot index is the rank that decides ties exactly as
 //            the reference's "first found wins" (strict <, :625) whatever order the kernel
-//            visits nodes in.  rem = triangles left in the leaf after this one;
+//            visits nodes in (rank = slot, stored explicitly so that a scene built with
+//            RT_ACCEL_SAH, whose slots follow another tree, resolves ties the same way).
+//            rem = triangles left in the leaf after this one;
 //            flags = mesh index | RT_TFB_BIT (the mesh's transparentFromBehind).
 //   tri_nrm  3 x float4 per slot (corner normals; .w of the first = mesh index).
 //   nodes    4 x float4 per INTERIOR node: both children's boxes and references
@@ -79,6 +81,8 @@ struct DevScene {
     const float4* roots;
     const MatDev* mats;
     const SphereDev* spheres;
+    const int* rank_slot;  // reference rank -> slot (identity unless the scene was built with RT_ACCEL_SAH)
+    const int* slot_id;    // triId of each slot
     int n_meshes;
     int n_spheres;
     int stack_depth;      // stack entries a lane can need (max tree depth + 1)
@@ -417,7 +421,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
                             // all rejects are folded into one predicate and the three edge tests run together:
                             // one divergent region instead of five nested ones (scalar-unit pressure)
-                            const bool tested = __float_as_int(g3.z) != prev_id;
+                            const int rank_k = __float_as_int(g3.z);       // rank in the reference's traversal order
+                            const bool tested = rank_k != prev_id;
                             if (STATS) cnt.tri += tested;
                             // hitBehind for this triangle's mesh (:605-615; in a solid: same mesh only [9.6])
                             // = in_solid ? mesh == prev_mesh : !transparentFromBehind, through the per-ray key/mask
@@ -429,7 +434,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             bool ok = tested && !(__builtin_fabsf(nd) < 1e-6f) && !(nd > 0.0f && !hb);
                             ok = ok && !(t < 1e-6f);                        // covers the reference's `t < 0` reject too
                             // closer than (or tied with a later-ranked) current best; NaN t never wins
-                            ok = ok && (t < tv.best_t || (t == tv.best_t && tv.k < tv.best_rank));
+                            ok = ok && (t < tv.best_t || (t == tv.best_t && rank_k < tv.best_rank));
                             if (ok) {
                                 const v3 P = madd3(org, t, dir);
                                 const float e0 = dot3(N, cross3(B - A, P - A));
@@ -437,7 +442,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 const float e2 = dot3(N, cross3(A - C, P - C));
                                 const bool inside = !(e0 < 0.0f) && !(e1 < 0.0f) && !(e2 < 0.0f);
                                 tv.best_t = inside ? t : tv.best_t;
-                                tv.best_rank = inside ? tv.k : tv.best_rank;
+                                tv.best_rank = inside ? rank_k : tv.best_rank;
                             }
                             tv.k = __float_as_int(g3.y) > 0 ? tv.k + 1 : -1;
                         }
@@ -457,7 +462,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     int id = -1;
                     if (tv.best_rank != RT_MISS_RANK) {
                         if (tv.best_rank < 0) id = -2 - (tv.best_rank - RT_SPHERE_RANK);
-                        else id = __float_as_int(S.tri_geo[4 * (size_t)tv.best_rank + 3].z);
+                        else id = PS.slot_id[PS.rank_slot[tv.best_rank]];
                     }
                     const size_t pix = (size_t)(pxy >> 16) * cam.width + (pxy & 0xffffu);
                     P.ids[pix] = id;
@@ -481,7 +486,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         normal = normalize3(hit_point - V3(sph.position[0], sph.position[1], sph.position[2]));
                         hit_mat = 256 + si;
                     } else {
-                        const float4* g = S.tri_geo + 4 * (size_t)tv.best_rank;
+                        const int slot = PS.rank_slot[tv.best_rank];
+                        const float4* g = S.tri_geo + 4 * (size_t)slot;
                         const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
                         const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
                         const v3 N = V3(g0.w, g1.w, g2.w);
@@ -490,7 +496,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         const float w = length3(cross3(B - A, hit_point - A)) / 2.0f / area;
                         const float u = length3(cross3(C - B, hit_point - B)) / 2.0f / area;
                         const float v = 1.0f - u - w;
-                        const float4* nn = PS.tri_nrm + 3 * (size_t)tv.best_rank;
+                        const float4* nn = PS.tri_nrm + 3 * (size_t)slot;
                         const float4 na = nn[0], nb = nn[1], nc = nn[2];
                         normal = V3(na.x * u + nb.x * v + nc.x * w, na.y * u + nb.y * v + nc.y * w,
                                     na.z * u + nb.z * v + nc.z * w);

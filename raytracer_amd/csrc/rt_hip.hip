@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/rt_hip.h"
+#include "rt_bvh_internal.h"
 #include "rt_dev_trace.h"
 
 // ----------------------------------------------------------------------------------------
@@ -39,7 +40,7 @@ struct PoseArgs {
     const float4* rest;      // 6 x float4 per slot: A, B, C, nA, nB, nC (rest pose)
     const int* slot_mesh;    // mesh of each slot
     const int* slot_rem;     // triangles left in the leaf after this one
-    const int* slot_id;      // triId of each slot
+    const int* slot_rank;    // rank of each slot in the reference's traversal order
     const float* xf;         // 16 floats per mesh, row-major, translation in row 3
     const unsigned char* dirty;  // per mesh: 1 = re-pose (0 = leave), 2 = copy rest (no transform yet)
     const MatDev* mats;      // per mesh (transparentFromBehind goes into the triangle's flag word)
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void k_pose(PoseArgs a) {
     g[1] = make_float4(B.x, B.y, B.z, N.y);
     g[2] = make_float4(C.x, C.y, C.z, N.z);
     const int flags = mesh | (a.mats[mesh].transparentFromBehind ? RT_TFB_BIT : 0);
-    g[3] = make_float4(d, __int_as_float(a.slot_rem[k]), __int_as_float(a.slot_id[k]), __int_as_float(flags));
+    g[3] = make_float4(d, __int_as_float(a.slot_rem[k]), __int_as_float(a.slot_rank[k]), __int_as_float(flags));
     float4* o = a.nrm + 3 * (size_t)k;
     o[0] = make_float4(n[0][0], n[0][1], n[0][2], __int_as_float(mesh));
     o[1] = make_float4(n[1][0], n[1][1], n[1][2], 0.0f);
@@ -154,12 +155,13 @@ __global__ __launch_bounds__(256) void k_pack_nodes(const PackInfo* pi, int n_re
 }
 
 // std140 read-back helpers
-__global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const float4* nrm, int n_slots, float* out28, int n_tris) {
+__global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const float4* nrm, const int* slot_id, int n_slots, float* out28, int n_tris) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_slots) return;
     float4 g0 = geo[4 * (size_t)k], g1 = geo[4 * (size_t)k + 1], g2 = geo[4 * (size_t)k + 2], g3 = geo[4 * (size_t)k + 3];
     float4 a = nrm[3 * (size_t)k], b = nrm[3 * (size_t)k + 1], c = nrm[3 * (size_t)k + 2];
-    int id = __float_as_int(g3.z);
+    int id = slot_id[k];
+    (void)g3;
     if (id < 0 || id >= n_tris) return;
     float* o = out28 + 28 * (size_t)id;
     o[0] = g0.x; o[1] = g0.y; o[2] = g0.z; o[4] = g1.x; o[5] = g1.y; o[6] = g1.z; o[8] = g2.x; o[9] = g2.y; o[10] = g2.z;
@@ -236,7 +238,7 @@ struct rt_ctx {
     char err[512] = {0};
     // scene (device)
     DevBuf<float4> rest, geo, nrm, nodes, roots, nbox;
-    DevBuf<int> slot_mesh, slot_rem, slot_id, level_nodes, root_v, root_ref;
+    DevBuf<int> slot_mesh, slot_rem, slot_id, slot_rank, rank_slot, level_nodes, root_v, root_ref;
     DevBuf<float> xf;
     DevBuf<unsigned char> dirty;
     DevBuf<VNode> vnodes;
@@ -259,6 +261,8 @@ struct rt_ctx {
     int n_tris = 0, n_slots = 0, n_meshes = 0, n_nodes = 0, n_visit = 0, n_rec = 0, n_spheres = 0;
     int stack_depth = 1;
     int tlas_above = 32;                  // scenes with more meshes than this get the top-level tree (the LDS root mask holds 32)
+    int accel = RT_ACCEL_REFERENCE;       // structure built by the next rt_set_scene (rt_set_accel)
+    bool scene_is_sah = false;
     int tlas_root = -1;                   // record of the top-level tree's root (scenes with > 32 meshes), else -1
     bool have_scene = false, have_cam = false, prep_pending = false;
     bool flags_pending = false;           // materials changed since the triangle flag words were written
@@ -333,7 +337,7 @@ int run_prep(rt_ctx* c) {
     HIPCK(c, hipMemcpyAsync(c->dirty.p, c->h_dirty.data(), c->h_dirty.size(), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));   // pageable sources: h_dirty is cleared below
     if (c->n_slots) {
-        PoseArgs pa{c->rest.p, c->slot_mesh.p, c->slot_rem.p, c->slot_id.p, c->xf.p, c->dirty.p, c->mats.p, c->geo.p, c->nrm.p, c->n_slots};
+        PoseArgs pa{c->rest.p, c->slot_mesh.p, c->slot_rem.p, c->slot_rank.p, c->xf.p, c->dirty.p, c->mats.p, c->geo.p, c->nrm.p, c->n_slots};
         hipLaunchKernelGGL(k_pose, dim3(blocks_for(c->n_slots)), dim3(256), 0, c->stream, pa);
     }
     if (c->flags_pending && c->n_slots)
@@ -358,7 +362,7 @@ int run_prep(rt_ctx* c) {
 DevScene scene_view(const rt_ctx* c) {
     DevScene s;
     s.tri_geo = c->geo.p; s.tri_nrm = c->nrm.p; s.nodes = c->nodes.p; s.roots = c->roots.p;
-    s.mats = c->mats.p; s.spheres = c->spheres.p; s.n_meshes = c->n_meshes; s.n_spheres = c->n_spheres;
+    s.mats = c->mats.p; s.spheres = c->spheres.p; s.rank_slot = c->rank_slot.p; s.slot_id = c->slot_id.p; s.n_meshes = c->n_meshes; s.n_spheres = c->n_spheres;
     s.stack_depth = c->stack_depth;
     s.tlas_root = c->tlas_root;
     return s;
@@ -487,7 +491,7 @@ int rt_create(int device, rt_ctx** out) {
 
 static void free_scene(rt_ctx* c) {
     c->rest.release(); c->geo.release(); c->nrm.release(); c->nodes.release(); c->roots.release(); c->nbox.release();
-    c->slot_mesh.release(); c->slot_rem.release(); c->slot_id.release(); c->level_nodes.release();
+    c->slot_mesh.release(); c->slot_rem.release(); c->slot_id.release(); c->slot_rank.release(); c->rank_slot.release(); c->level_nodes.release();
     c->root_v.release(); c->root_ref.release(); c->xf.release(); c->dirty.release(); c->vnodes.release();
     c->pack.release(); c->mats.release(); c->spheres.release();
     c->have_scene = false;
@@ -548,65 +552,126 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     std::vector<int> root_v(n_meshes), root_ref(n_meshes);
     std::vector<float4> rest;
     std::vector<int> slot_mesh, slot_rem, slot_id;
-    std::vector<int> first_visit(n_nodes, -1);
+    std::vector<int> first_visit;
     std::vector<std::pair<int, int>> tlas_vnode_of_rec;
-    const size_t visit_cap = 4 * (size_t)n_nodes + 16;
     int max_depth = 0;
-    for (int j = 0; j < n_meshes; j++) {
-        std::vector<Visit> st;
-        st.push_back({meshes[j].node0Id, 0, -1, 0});
-        while (!st.empty()) {
-            Visit cur = st.back();
-            st.pop_back();
-            if (vnodes.size() >= visit_cap) return fail(c, RT_E_LIMIT, "BVH is not a tree (shared sub-graphs blow up)");
-            const Std140Node& n = nodes[cur.node];
-            int v = (int)vnodes.size();
-            vnodes.push_back({-1, -1, 0, 0});
-            vdepth.push_back(cur.depth);
-            vnode_id.push_back(cur.node);
-            if (first_visit[cur.node] < 0) first_visit[cur.node] = v;
-            if (cur.depth > max_depth) max_depth = cur.depth;
-            if (cur.depth + 1 > RT_MAX_STACK) return fail(c, RT_E_LIMIT, "mesh %d: BVH deeper than %d", j, RT_MAX_STACK - 1);
-            int ref;
-            const bool leaf = n.c1 < 0 && n.c2 < 0;
-            if (leaf) {
-                vnodes[v].start = (int)slot_id.size();
-                vnodes[v].count = n.cnt;
-                for (int i = 0; i < n.cnt; i++) {
-                    const Std140Tri& t = tris[leaf_ids[n.off + i]];
-                    if (t.meshIndex != j)
-                        return fail(c, RT_E_ARG, "triangle %d in the BVH of mesh %d belongs to mesh %d", t.triId, j, t.meshIndex);
-                    const float* src[6] = {t.posA, t.posB, t.posC, t.nA, t.nB, t.nC};
-                    for (int q = 0; q < 6; q++) rest.push_back(make_float4(src[q][0], src[q][1], src[q][2], 0.f));
-                    slot_mesh.push_back(j);
-                    slot_rem.push_back(n.cnt - 1 - i);
-                    slot_id.push_back(t.triId);
+    // walks the trees `wn` (roots `wroot[j]`, leaf lists in `wids`) and fills the vectors above
+    auto walk = [&](const Std140Node* wn, int wn_count, const int32_t* wids, const std::vector<int>& wroot) -> int {
+        vnodes.clear(); vdepth.clear(); vnode_id.clear(); pack.clear(); rest.clear();
+        slot_mesh.clear(); slot_rem.clear(); slot_id.clear();
+        first_visit.assign(wn_count, -1);
+        max_depth = 0;
+        const size_t visit_cap = 4 * (size_t)wn_count + 16;
+        for (int j = 0; j < n_meshes; j++) {
+            std::vector<Visit> st;
+            st.push_back({wroot[j], 0, -1, 0});
+            while (!st.empty()) {
+                Visit cur = st.back();
+                st.pop_back();
+                if (vnodes.size() >= visit_cap) return fail(c, RT_E_LIMIT, "BVH is not a tree (shared sub-graphs blow up)");
+                const Std140Node& n = wn[cur.node];
+                int v = (int)vnodes.size();
+                vnodes.push_back({-1, -1, 0, 0});
+                vdepth.push_back(cur.depth);
+                vnode_id.push_back(cur.node);
+                if (first_visit[cur.node] < 0) first_visit[cur.node] = v;
+                if (cur.depth > max_depth) max_depth = cur.depth;
+                if (cur.depth + 1 > RT_MAX_STACK) return fail(c, RT_E_LIMIT, "mesh %d: BVH deeper than %d", j, RT_MAX_STACK - 1);
+                int ref;
+                const bool leaf = n.c1 < 0 && n.c2 < 0;
+                if (leaf) {
+                    vnodes[v].start = (int)slot_id.size();
+                    vnodes[v].count = n.cnt;
+                    for (int i = 0; i < n.cnt; i++) {
+                        const Std140Tri& t = tris[wids[n.off + i]];
+                        if (t.meshIndex != j)
+                            return fail(c, RT_E_ARG, "triangle %d in the BVH of mesh %d belongs to mesh %d", t.triId, j, t.meshIndex);
+                        const float* src[6] = {t.posA, t.posB, t.posC, t.nA, t.nB, t.nC};
+                        for (int q = 0; q < 6; q++) rest.push_back(make_float4(src[q][0], src[q][1], src[q][2], 0.f));
+                        slot_mesh.push_back(j);
+                        slot_rem.push_back(n.cnt - 1 - i);
+                        slot_id.push_back(t.triId);
+                    }
+                    ref = n.cnt > 0 ? ~vnodes[v].start : RT_NONE;     // an empty leaf contributes nothing
+                } else {
+                    ref = (int)pack.size();
+                    pack.push_back({-1, -1, RT_NONE, RT_NONE});
+                    // push first child first so that the second child is visited first
+                    if (n.c1 >= 0) st.push_back({n.c1, cur.depth + 1, ref, 1});
+                    if (n.c2 >= 0) st.push_back({n.c2, cur.depth + 1, ref, 2});
                 }
-                ref = n.cnt > 0 ? ~vnodes[v].start : RT_NONE;     // an empty leaf contributes nothing
-            } else {
-                ref = (int)pack.size();
-                pack.push_back({-1, -1, RT_NONE, RT_NONE});
-                // push first child first so that the second child is visited first
-                if (n.c1 >= 0) st.push_back({n.c1, cur.depth + 1, ref, 1});
-                if (n.c2 >= 0) st.push_back({n.c2, cur.depth + 1, ref, 2});
+                if (cur.parent_rec < 0) { root_v[j] = v; root_ref[j] = ref; }
+                else if (cur.which == 1) { pack[cur.parent_rec].c1 = v; pack[cur.parent_rec].ref1 = ref; }
+                else { pack[cur.parent_rec].c2 = v; pack[cur.parent_rec].ref2 = ref; }
             }
-            if (cur.parent_rec < 0) { root_v[j] = v; root_ref[j] = ref; }
-            else if (cur.which == 1) { pack[cur.parent_rec].c1 = v; pack[cur.parent_rec].ref1 = ref; }
-            else { pack[cur.parent_rec].c2 = v; pack[cur.parent_rec].ref2 = ref; }
         }
-    }
-    // child visit indices for the refit (vnode.c1/c2), from the pack table
-    {
+        // child visit indices for the refit (vnode.c1/c2), from the pack table
         int rec = 0;
         for (size_t v = 0; v < vnodes.size(); v++) {
-            const Std140Node& n = nodes[vnode_id[v]];
+            const Std140Node& n = wn[vnode_id[v]];
             if (!(n.c1 < 0 && n.c2 < 0)) {
                 vnodes[v].c1 = pack[rec].c1;
                 vnodes[v].c2 = pack[rec].c2;
                 rec++;
             }
         }
+        return RT_OK;
+    };
+    std::vector<int> ref_roots(n_meshes);
+    for (int j = 0; j < n_meshes; j++) ref_roots[j] = meshes[j].node0Id;
+    int wrc = walk(nodes, n_nodes, leaf_ids, ref_roots);
+    if (wrc) return wrc;
+    // rank = position in the reference's traversal order: what decides ties (rt_dev_trace.h)
+    std::vector<int> slot_rank(slot_id.size()), rank_slot(slot_id.size());
+    for (size_t k = 0; k < slot_id.size(); k++) slot_rank[k] = rank_slot[k] = (int)k;
+    const std::vector<int> ref_first_visit = first_visit;
+    const bool sah = c->accel == RT_ACCEL_SAH && !slot_id.empty();
+    if (sah) {
+        // ---- opt-in performance structure: a binned-SAH tree per mesh over the same triangles ----
+        // Same slots machinery, other topology; every triangle keeps the rank the reference's
+        // traversal gave it, so equal-distance hits still resolve as the shader's.  What changes is
+        // WHICH boxes are tested: a hit can differ from the exact modes where the reference's own
+        // leaf box misses a triangle by rounding.
+        std::vector<int> rank_of_tri(n_tris, -1);
+        for (size_t k = 0; k < slot_id.size(); k++)
+            if (rank_of_tri[slot_id[k]] < 0) rank_of_tri[slot_id[k]] = (int)k;
+        std::vector<RtNode48> sn;
+        std::vector<int32_t> sids;
+        std::vector<int> sroots(n_meshes);
+        {
+            std::vector<std::vector<int32_t>> per_mesh(n_meshes);
+            for (size_t k = 0; k < slot_id.size(); k++)
+                if (rank_of_tri[slot_id[k]] == (int)k) per_mesh[slot_mesh[k]].push_back(slot_id[k]);
+            for (int j = 0; j < n_meshes; j++) {
+                const std::vector<int32_t>& ids = per_mesh[j];
+                if (ids.empty()) {                                   // keep the (empty) reference leaf
+                    RtNode48 e;
+                    std::memset(&e, 0, sizeof(e));
+                    e.id = (int32_t)sn.size(); e.c1 = e.c2 = -1; e.off = 0; e.cnt = 0;
+                    sroots[j] = e.id;
+                    sn.push_back(e);
+                    continue;
+                }
+                std::vector<float> pos9(9 * ids.size());
+                for (size_t i = 0; i < ids.size(); i++) {
+                    const Std140Tri& t = tris[ids[i]];
+                    const float* src[3] = {t.posA, t.posB, t.posC};
+                    for (int q = 0; q < 3; q++)
+                        for (int a = 0; a < 3; a++) pos9[9 * i + 3 * q + a] = src[q][a];
+                }
+                sroots[j] = rt_sah_build(pos9.data(), ids.data(), (int)ids.size(), RT_MAX_STACK - 2, sn, sids);
+            }
+        }
+        static_assert(sizeof(RtNode48) == sizeof(Std140Node), "node images");
+        if ((wrc = walk((const Std140Node*)sn.data(), (int)sn.size(), sids.data(), sroots))) return wrc;
+        slot_rank.resize(slot_id.size());
+        rank_slot.assign(n_tris > 0 ? (size_t)*std::max_element(rank_of_tri.begin(), rank_of_tri.end()) + 1 : 0, 0);
+        for (size_t k = 0; k < slot_id.size(); k++) {
+            slot_rank[k] = rank_of_tri[slot_id[k]];
+            rank_slot[slot_rank[k]] = (int)k;
+        }
     }
+    first_visit = ref_first_visit;          // rt_read_nodes48 maps the REFERENCE's nodes (unavailable with RT_ACCEL_SAH)
     // ---- more than 32 meshes: a top-level tree over the mesh roots replaces the flat mesh loop ----
     // Its interior nodes are ordinary 64-byte records whose leaf children ARE the mesh roots
     // (same box, same reference), so the traversal needs nothing new; their boxes are refit with
@@ -690,6 +755,8 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     if ((rc = upload(c, c->slot_mesh, slot_mesh))) return rc;
     if ((rc = upload(c, c->slot_rem, slot_rem))) return rc;
     if ((rc = upload(c, c->slot_id, slot_id))) return rc;
+    if ((rc = upload(c, c->slot_rank, slot_rank))) return rc;
+    if ((rc = upload(c, c->rank_slot, rank_slot))) return rc;
     if ((rc = upload(c, c->vnodes, vnodes))) return rc;
     if ((rc = upload(c, c->pack, pack))) return rc;
     if ((rc = upload(c, c->level_nodes, level_nodes))) return rc;
@@ -714,6 +781,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     c->level_off = level_off;
     c->stack_depth = max_depth + 1;
     c->tlas_root = tlas_root;
+    c->scene_is_sah = sah;
     c->node_first_visit = first_visit;
     c->h_nodes.assign(nodes, nodes + n_nodes);
     c->have_scene = true;
@@ -768,7 +836,7 @@ int rt_read_tris28(rt_ctx* c, float* out) {
     HIPCK(c, hipMemsetAsync(tmp.p, 0, 28 * (size_t)std::max(c->n_tris, 1) * 4, c->stream));
     if (c->n_slots)
         hipLaunchKernelGGL(k_gather_tris28, dim3(blocks_for(c->n_slots)), dim3(256), 0, c->stream, c->geo.p, c->nrm.p,
-                           c->n_slots, tmp.p, c->n_tris);
+                           c->slot_id.p, c->n_slots, tmp.p, c->n_tris);
     hipError_t e = hipMemcpyAsync(out, tmp.p, 28 * (size_t)c->n_tris * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     tmp.release();
@@ -788,6 +856,7 @@ int rt_read_tris28(rt_ctx* c, float* out) {
 int rt_read_nodes48(rt_ctx* c, void* out) {
     if (!c || !out) return RT_E_ARG;
     if (!c->have_scene) return fail(c, RT_E_STATE, "no scene");
+    if (c->scene_is_sah) return fail(c, RT_E_STATE, "the reference's nodes are not on the device in a scene built with RT_ACCEL_SAH");
     HIPCK(c, hipSetDevice(c->device));
     int rc = run_prep(c);
     if (rc) return rc;
@@ -964,6 +1033,13 @@ int rt_read_mean(rt_ctx* c, float* out) {
         const size_t n = (size_t)c->cam.width * c->cam.height * 3;
         for (size_t i = 0; i < n; i++) out[i] = out[i] / d;
     }
+    return RT_OK;
+}
+
+int rt_set_accel(rt_ctx* c, int accel) {
+    if (!c) return RT_E_ARG;
+    if (accel != RT_ACCEL_REFERENCE && accel != RT_ACCEL_SAH) return fail(c, RT_E_ARG, "unknown acceleration structure %d", accel);
+    c->accel = accel;            // takes effect at the next rt_set_scene
     return RT_OK;
 }
 

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "rt_read_mean": (C.c_int, [_vp, _vp]),
     "rt_set_accum_passes": (C.c_int, [_vp, C.c_uint64]),
     "rt_set_cull": (C.c_int, [_vp, C.c_int]),
+    "rt_set_accel": (C.c_int, [_vp, C.c_int]),
     "rt_enable_stats": (C.c_int, [_vp, C.c_int]),
     "rt_reset_stats": (C.c_int, [_vp]),
     "rt_get_stats": (C.c_int, [_vp, C.POINTER(RtStats)]),
@@ -250,6 +251,10 @@ class RtContext:
         return out
 
     # -- counters ------------------------------------------------------------------------------------
+    def set_accel(self, sah: bool) -> None:
+        """Structure the NEXT set_scene builds: False = the reference's BVH (parity), True = SAH."""
+        self._ck(self.lib.dll.rt_set_accel(self._h, 1 if sah else 0), "rt_set_accel")
+
     def set_cull(self, on: bool) -> None:
         self._ck(self.lib.dll.rt_set_cull(self._h, int(on)), "rt_set_cull")
 
