@@ -209,7 +209,7 @@ struct SahBuilder {
     std::vector<SahPrim> prims;
     std::vector<RtNode48>* nodes;
     std::vector<int32_t>* leaf_ids;
-    int max_depth;
+    int max_depth, max_leaf;
 
     int build(int b, int e, int depth) {
         const int ni = (int)nodes->size();
@@ -221,7 +221,7 @@ struct SahBuilder {
         nd.id = ni; nd.c1 = nd.c2 = -1; nd.off = -1; nd.cnt = e - b;
         nodes->push_back(nd);
         const int n = e - b;
-        if (n <= 4 || depth >= max_depth) return make_leaf(ni, b, e);
+        if (n <= max_leaf || depth >= max_depth) return make_leaf(ni, b, e);
         // best of 3 axes x 15 bin boundaries
         constexpr int NB = 16;
         float best_cost = INFINITY;
@@ -278,9 +278,10 @@ struct SahBuilder {
 
 }  // namespace
 
-int rt_sah_build(const float* pos9, const int32_t* tri_ids, int n, int max_depth, std::vector<RtNode48>& nodes,
+int rt_sah_build(const float* pos9, const int32_t* tri_ids, int n, int max_depth, int max_leaf, std::vector<RtNode48>& nodes,
                  std::vector<int32_t>& leaf_ids) {
     SahBuilder sb;
+    sb.max_leaf = max_leaf;
     sb.nodes = &nodes;
     sb.leaf_ids = &leaf_ids;
     sb.max_depth = max_depth;

@@ -13,9 +13,9 @@ struct RtNode48 {
 static_assert(sizeof(RtNode48) == 48, "std140 GraphNode");
 
 // Binned-SAH BVH over `n` triangles (pos9 = 9 floats each) for the opt-in performance structure
-// (RT_ACCEL_SAH): leaves of at most 4 triangles, depth <= max_depth.  Appends nodes (ids continue
+// (RT_ACCEL_SAH): leaves of at most max_leaf triangles, depth <= max_depth.  Appends nodes (ids continue
 // at nodes.size(), children after their parent) and leaf entries (tri_ids[i] of the triangles, in
 // leaf order) to the output vectors; returns the id of the root.  The reference's split rule
 // (rt_bvh_build) stays the parity structure.
-int rt_sah_build(const float* pos9, const int32_t* tri_ids, int n, int max_depth, std::vector<RtNode48>& nodes,
+int rt_sah_build(const float* pos9, const int32_t* tri_ids, int n, int max_depth, int max_leaf, std::vector<RtNode48>& nodes,
                  std::vector<int32_t>& leaf_ids);

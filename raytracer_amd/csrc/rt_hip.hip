@@ -263,6 +263,7 @@ struct rt_ctx {
     int tlas_above = 32;                  // scenes with more meshes than this get the top-level tree (the LDS root mask holds 32)
     int accel = RT_ACCEL_REFERENCE;       // structure built by the next rt_set_scene (rt_set_accel)
     bool scene_is_sah = false;
+    int sah_leaf = 4;                     // triangles per SAH leaf (RT_SAH_LEAF)
     int tlas_root = -1;                   // record of the top-level tree's root (scenes with > 32 meshes), else -1
     bool have_scene = false, have_cam = false, prep_pending = false;
     bool flags_pending = false;           // materials changed since the triangle flag words were written
@@ -472,6 +473,7 @@ int rt_create(int device, rt_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
     c->stream = c->own_stream;
+    if (const char* e = getenv("RT_SAH_LEAF")) c->sah_leaf = std::max(1, std::min(64, atoi(e)));
     if (const char* e = getenv("RT_TLAS_ABOVE")) c->tlas_above = std::max(1, std::min(32, atoi(e)));
     if (const char* e = getenv("RT_NODE_BIAS")) c->node_bias = atoi(e);
     if (const char* e = getenv("RT_BURST8")) c->burst8 = std::max(0, std::min(64, atoi(e)));
@@ -659,7 +661,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
                     for (int q = 0; q < 3; q++)
                         for (int a = 0; a < 3; a++) pos9[9 * i + 3 * q + a] = src[q][a];
                 }
-                sroots[j] = rt_sah_build(pos9.data(), ids.data(), (int)ids.size(), RT_MAX_STACK - 2, sn, sids);
+                sroots[j] = rt_sah_build(pos9.data(), ids.data(), (int)ids.size(), RT_MAX_STACK - 2, c->sah_leaf, sn, sids);
             }
         }
         static_assert(sizeof(RtNode48) == sizeof(Std140Node), "node images");

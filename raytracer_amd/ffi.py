@@ -296,6 +296,21 @@ class RtContext:
                 self.update_mesh_pose(mesh.id, mesh.csys.pos, mesh.csys.quat)
                 mesh.unflag_for_mesh_update()
 
+    def update_scene(self, scene) -> None:
+        """Per-frame update of an uploaded scene (what the reference re-uploads each frame,
+        application.py:939-976): poses of the meshes flagged for update, every material."""
+        from .scripts.classes import MESH_DTYPE
+
+        for mesh in scene.meshes:
+            if mesh.is_awaiting_mesh_update:
+                self.update_mesh_pose(mesh.id, mesh.csys.pos, mesh.csys.quat)
+                mesh.unflag_for_mesh_update()
+        recs = np.zeros(len(scene.meshes), dtype=MESH_DTYPE)
+        for i, m in enumerate(scene.meshes):
+            recs[i]["index"] = m.id
+            recs[i]["material"] = m.material.as_record()
+        self.set_materials(recs, scene.atmosphere_material.as_record().reshape(1))
+
     def load_camera(self, cam) -> None:
         from .scripts import functions as F
 

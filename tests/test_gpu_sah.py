@@ -1,0 +1,83 @@
+"""The opt-in SAH structure (rt_set_accel(RT_ACCEL_SAH)): same triangles, same tie ranks, other
+boxes.  Its hits can differ from the reference structure only where the reference's own leaf box
+misses a triangle by rounding (or the other way round), so the tests count differing pixels
+instead of demanding zero - and demand zero where zero is what was measured (the bench frame)."""
+import numpy as np
+import pytest
+
+from conftest import build_suzanne
+from test_gpu_fuzz import random_scene
+from synth import stress_scene
+
+
+def _ctx(lib, sc, w, h, sah, cull):
+    c = lib.create()
+    c.set_accel(sah)
+    c.load_scene(sc)
+    c.load_camera(sc.cam)
+    c.resize(w, h)
+    c.set_cull(cull)
+    return c
+
+
+def _render(lib, sc, w, h, sah, cull, passes, rpp, bounces):
+    c = _ctx(lib, sc, w, h, sah, cull)
+    c.enable_stats(True)
+    ids, ts = c.first_hit(1)
+    c.render(1, passes, 1, rpp, bounces, 0)
+    return ids, ts, c.read_mean(), c.stats()
+
+
+@pytest.mark.gpu
+def test_sah_on_random_scenes(hip_lib):
+    tot = bad = 0
+    for seed in range(1, 25):
+        w, h = 96, 54
+        a = _render(hip_lib, random_scene(seed), w, h, False, False, 2, 2, 6)
+        b = _render(hip_lib, random_scene(seed), w, h, True, True, 2, 2, 6)
+        d_ids = int((a[0] != b[0]).sum())
+        d_px = int((a[2].view(np.uint32) != b[2].view(np.uint32)).any(axis=2).sum())
+        tot += w * h
+        bad += d_px
+        assert d_ids <= 2 and d_px <= 5, f"seed {seed}: {d_ids} first hits, {d_px} pixels differ"
+        assert b[3]["tri_tests"] < a[3]["tri_tests"]
+    print(f"SAH vs reference structure on 24 random scenes: {bad} of {tot} pixels differ")
+
+
+@pytest.mark.gpu
+def test_sah_stress_scene_and_pose_updates(hip_lib):
+    a = _render(hip_lib, stress_scene(), 160, 90, False, False, 3, 2, 8)
+    b = _render(hip_lib, stress_scene(), 160, 90, True, True, 3, 2, 8)
+    d = int((a[2].view(np.uint32) != b[2].view(np.uint32)).any(axis=2).sum())
+    print(f"stress scene: {d} of {160*90} pixels differ")
+    assert d <= 5 and a[3]["rays"] > 0
+    # animation: pose and material updates reach the SAH structure too (device refit of ITS boxes)
+    sc0, sc1 = build_suzanne(0), build_suzanne(0)
+    ref = _ctx(hip_lib, sc0, 160, 90, False, False)
+    sah = _ctx(hip_lib, sc1, 160, 90, True, True)
+    for frame in (0, 37, 90):
+        for sc, ctx in ((sc0, ref), (sc1, sah)):
+            sc.animate_frame(frame)
+            ctx.update_scene(sc)
+            ctx.load_camera(sc.cam)
+            ctx.reset_accum()
+            ctx.render(1, 2, 1, 1, 4, 0)
+        assert np.array_equal(ref.read_mean().view(np.uint32), sah.read_mean().view(np.uint32)), f"frame {frame}"
+    with pytest.raises(Exception):
+        from raytracer_amd.scripts.scenes.chunker import NODE_DTYPE
+        sah.read_nodes48(NODE_DTYPE)            # the reference's nodes are not on the device in SAH mode
+    assert np.array_equal(ref.read_tris28().view(np.uint32), sah.read_tris28().view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_sah_bench_frame_is_pixel_identical(hip_lib):
+    """What bench.py relies on: on configs[1] the SAH + culled traversal renders the very image of
+    the reference structure's exact traversal, first hits included."""
+    w, h = 1920, 1080
+    a = _render(hip_lib, build_suzanne(0), w, h, False, False, 64, 1, 4)
+    b = _render(hip_lib, build_suzanne(0), w, h, True, True, 64, 1, 4)
+    assert a[3]["rays"] == b[3]["rays"] == 634615464 + w * h      # 64 passes + the first-hit probe
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    print(f"triangle tests per ray {a[3]['tri_tests']/a[3]['rays']:.1f} -> {b[3]['tri_tests']/b[3]['rays']:.1f}, "
+          f"box tests per ray {a[3]['box_tests']/a[3]['rays']:.1f} -> {b[3]['box_tests']/b[3]['rays']:.1f}")

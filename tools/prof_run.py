@@ -23,6 +23,7 @@ else:
     sc = S.build()
 sc.animate_frame(0)
 ctx = lib.create(0)
+ctx.set_accel(os.environ.get('RT_SAH', '0') == '1')
 ctx.load_scene(sc)
 ctx.load_camera(sc.cam)
 ctx.resize(w, h)
