@@ -83,6 +83,7 @@ struct DevScene {
     const SphereDev* spheres;
     const int* rank_slot;  // reference rank -> slot (identity unless the scene was built with RT_ACCEL_SAH)
     const int* slot_id;    // triId of each slot
+    const float4* tri_box; // RT_ACCEL_SAH only: 2 x float4 per slot = the box of the triangle's leaf in the REFERENCE's tree
     int n_meshes;
     int n_spheres;
     int stack_depth;      // stack entries a lane can need (max tree depth + 1)
@@ -145,6 +146,33 @@ __device__ __forceinline__ bool culled(float tmin, float tmax, float best_t) {
     return (tmax < RT_CULL_BEHIND) || (tmin > fma_(best_t, RT_CULL_REL, best_t) + RT_CULL_ABS);
 }
 
+// SAH structure only.  Its boxes are not the reference's, so their slab tests are made
+// conservative: a box counts as hit when  tmin <= tmax + (e2 + 2^-16 max|o|) * max|1/d|, where
+// e2 = 2 * (2^-16 max|box coordinate| + 2^-20) is stored with the box.  That is the slab test of
+// the box widened by at least e2/2 + 2^-17 max|o| on every side (each axis widens its interval
+// by e|1/d_a| <= e max|1/d|), ~100 x the rounding of the slab and edge arithmetic, so a ray whose
+// triangle test can pass always reaches the triangle.  The unwidened [tmin, tmax] still drives
+// the culling rules and the near-first order.  Which triangles COUNT is decided by the
+// reference's own leaf box (tri_box, see the path block).
+__device__ __forceinline__ float sah_slack(v3 o, v3 inv) {
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(inv.x), __builtin_fabsf(inv.y)), __builtin_fabsf(inv.z));
+}
+__device__ __forceinline__ float sah_org(v3 o) {
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z)) * 0x1p-16f;
+}
+__device__ __forceinline__ bool sah_widened_hit(float tmin, float tmax, float e2, float mo, float mi) {
+    return tmin <= fma_(e2 + mo, mi, tmax);
+}
+// a ray with an exactly zero direction component (slab values may be NaN): the reference's
+// ladder on the box widened in space
+__device__ __forceinline__ bool sah_box_test_any(v3 o, v3 inv, float4 lo, float4 hi, float e2, float mo, float& tmin_out, float& tmax_out) {
+    const float e = e2 * 0.5f + mo;
+    float ta, tb;
+    const bool h = box_test(o, inv, make_float4(lo.x - e, lo.y - e, lo.z - e, 0.f), make_float4(hi.x + e, hi.y + e, hi.z + e, 0.f), ta, tb);
+    box_test(o, inv, lo, hi, tmin_out, tmax_out);
+    return h;
+}
+
 // Entry distance of a deferred child, kept in 16 bits (LDS is what limits occupancy here): the
 // top half of the binary32 pattern.  Truncation rounds a positive distance down, so the re-check
 // when the child is taken up can only cull less than the full value would; a negative distance
@@ -192,6 +220,7 @@ struct TraceArgs {
     uint32_t n_chunks, n_bx, n_by;   // chunks = n_passes x n_by x n_bx blocks of 16x16 pixels
     uint32_t first_pass, n_passes, pass_stride;
     int rays_per_pixel, max_bounces, sum_mode;
+    int recheck_all;              // SAH, tests only: repeat every query that hit a triangle with the per-hit check on
     int refill_below;             // traversal yields to the path block when fewer lanes than this traverse
     int node_bias;                // a node step is taken when cN + node_bias > cT
     int burst8;                   // a triangle burst lasts while 8 * (lanes with leaf work) >= burst8 * (lanes traversing at the vote)
@@ -227,8 +256,9 @@ struct Trav {
 // interior root the test is an exact shortcut: child boxes nest inside it and float
 // subtract/multiply are monotonic, so no child test could pass when the root test fails.
 template <bool STATS, bool CULL, bool FINITE>
-__device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn, v3 org, v3 inv, float best_t, Counters& cnt) {
+__device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn, v3 org, v3 inv, float best_t, bool sah, Counters& cnt) {
     uint32_t mask = 0;
+    const float mi = sah_slack(org, inv), mo = sah_org(org);
     // One box per trip, not unrolled: the kernel is issue bound, so overlapping the LDS latency
     // of several boxes buys nothing, while two or three boxes in flight cost spilled registers
     // (0.8 GB of scratch writes per frame, measured).
@@ -245,7 +275,10 @@ __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn
 #pragma unroll
         for (int u = 0; u < NB; u++) {
             float ta, tb;
-            const bool h = FINITE ? box_test_finite(org, inv, lo[u], hi[u], ta, tb) : box_test(org, inv, lo[u], hi[u], ta, tb);
+            bool h;
+            if (!sah) h = FINITE ? box_test_finite(org, inv, lo[u], hi[u], ta, tb) : box_test(org, inv, lo[u], hi[u], ta, tb);
+            else if (FINITE) { box_test_finite(org, inv, lo[u], hi[u], ta, tb); h = sah_widened_hit(ta, tb, hi[u].w, mo, mi); }
+            else h = sah_box_test_any(org, inv, lo[u], hi[u], hi[u].w, mo, ta, tb);
             const bool real = __float_as_int(lo[u].w) != RT_NONE && b0 + u < jn;
             const bool take = real && h && !culled<CULL>(ta, tb, best_t);
             if (STATS) cnt.box += real;
@@ -256,14 +289,26 @@ __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn
 }
 
 template <bool STATS, bool CULL>
-__device__ __forceinline__ uint32_t root_mask(int jn, const float4* s_roots, v3 org, v3 inv, float best_t, Counters& cnt) {
+__device__ __forceinline__ uint32_t root_mask(int jn, const float4* s_roots, v3 org, v3 inv, float best_t, bool sah, Counters& cnt) {
     // wave-uniform choice of the slab-test form (see box_test_finite)
     const bool all_finite = __ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0;
-    return all_finite ? root_mask_loop<STATS, CULL, true>(s_roots, jn, org, inv, best_t, cnt)
-                      : root_mask_loop<STATS, CULL, false>(s_roots, jn, org, inv, best_t, cnt);
+    return all_finite ? root_mask_loop<STATS, CULL, true>(s_roots, jn, org, inv, best_t, sah, cnt)
+                      : root_mask_loop<STATS, CULL, false>(s_roots, jn, org, inv, best_t, sah, cnt);
 }
 
-template <bool STATS, bool CULL, bool FIRST_HIT>
+// SAH structure: the reference only ever tests a triangle whose leaf box IN ITS OWN TREE the ray's
+// slab test passes (the boxes above it nest and float subtract/multiply are monotonic, so they
+// pass too).  The winner found through our tree is checked against that box (tri_box: 2 float4 per
+// slot); in the rounding-level case (~1e-9 of queries) that it fails, the query is run again with
+// the check applied to every hit (`gated`), so that the candidate set is exactly the reference's
+// (DESIGN.md 5).
+__device__ __forceinline__ bool ref_leaf_box_passes(const DevScene& S, int slot, v3 org, v3 inv) {
+    const float4* rb = (const float4*)((const char*)S.tri_box + ((uint32_t)slot << 5));
+    float ta, tb;
+    return box_test(org, inv, rb[0], rb[1], ta, tb);
+}
+
+template <bool STATS, bool CULL, bool FIRST_HIT, bool SAH>
 __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) {
     const DevScene& S = a.scene;
     // ---- LDS: mesh root table (2 float4 per mesh), then the per-lane columns
@@ -316,6 +361,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     float ior = 1.0f;
     bool in_solid = false;
     int hb_key = 0;            // hitBehind test of the ray in flight: the mesh it is inside, or 0 (set at query start)
+    constexpr bool sah = SAH;  // the scene was built with RT_ACCEL_SAH (S.tri_box is set)
+    bool gated = false;        // SAH: the query in flight is a repeat with the reference-leaf-box gate on every hit
     Trav tv;
     tv.cur = RT_NONE; tv.sp = 0; tv.lq = 0; tv.k = -1; tv.mask = 0; tv.node_live = false;
     tv.best_t = 1e20f; tv.best_rank = RT_MISS_RANK;
@@ -365,9 +412,18 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         if (__ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0) {
                             h1 = box_test_finite(org, inv, n0, n1, t1a, t1b);
                             h2 = box_test_finite(org, inv, n2, n3, t2a, t2b);
-                        } else {                                    // a lane has an exactly zero direction component
+                            if (sah) {
+                                const float mi = sah_slack(org, inv), mo = sah_org(org);
+                                h1 = sah_widened_hit(t1a, t1b, n2.w, mo, mi);
+                                h2 = sah_widened_hit(t2a, t2b, n3.w, mo, mi);
+                            }
+                        } else if (!sah) {                          // a lane has an exactly zero direction component
                             h1 = box_test(org, inv, n0, n1, t1a, t1b);
                             h2 = box_test(org, inv, n2, n3, t2a, t2b);
+                        } else {
+                            const float mo = sah_org(org);
+                            h1 = sah_box_test_any(org, inv, n0, n1, n2.w, mo, t1a, t1b);
+                            h2 = sah_box_test_any(org, inv, n2, n3, n3.w, mo, t2a, t2b);
                         }
                         h1 = h1 && ref1 != RT_NONE && !culled<CULL>(t1a, t1b, tv.best_t);
                         h2 = h2 && ref2 != RT_NONE && !culled<CULL>(t2a, t2b, tv.best_t);
@@ -440,7 +496,17 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 const float e0 = dot3(N, cross3(B - A, P - A));
                                 const float e1 = dot3(N, cross3(C - B, P - B));
                                 const float e2 = dot3(N, cross3(A - C, P - C));
-                                const bool inside = !(e0 < 0.0f) && !(e1 < 0.0f) && !(e2 < 0.0f);
+                                bool inside = !(e0 < 0.0f) && !(e1 < 0.0f) && !(e2 < 0.0f);
+                                // SAH structure, a query that is being repeated (see the path block): a hit
+                                // counts only if the ray passes the box of the triangle's leaf in the
+                                // REFERENCE's tree
+                                if (SAH && __ballot(gated && inside) != 0) {
+                                    if (gated && inside) {
+                                        const float4* rb = (const float4*)((const char*)S.tri_box + ((uint32_t)tv.k << 5));
+                                        float ta, tb;
+                                        inside = box_test(org, inv, rb[0], rb[1], ta, tb);
+                                    }
+                                }
                                 tv.best_t = inside ? t : tv.best_t;
                                 tv.best_rank = inside ? rank_k : tv.best_rank;
                             }
@@ -455,25 +521,31 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
 
         // =============== path phase: shade the finished query, start the next one ===============
         if (STATS) { sch.path_steps++; sch.path_lanes += __popcll(__ballot(mode == M_PATH)); }
-        bool need = false, start = false;
+        bool need = false, start = false, redo = false;
         if (mode == M_PATH) {
             if (!fresh) {
                 if (FIRST_HIT) {
                     int id = -1;
                     if (tv.best_rank != RT_MISS_RANK) {
                         if (tv.best_rank < 0) id = -2 - (tv.best_rank - RT_SPHERE_RANK);
-                        else id = PS.slot_id[PS.rank_slot[tv.best_rank]];
+                        else {
+                            const int slot = PS.rank_slot[tv.best_rank];
+                            id = PS.slot_id[slot];
+                            if (SAH && !gated) redo = !ref_leaf_box_passes(PS, slot, org, inv) || P.recheck_all != 0;
+                        }
                     }
-                    const size_t pix = (size_t)(pxy >> 16) * cam.width + (pxy & 0xffffu);
-                    P.ids[pix] = id;
-                    P.ts[pix] = tv.best_t;
-                    have = false;
-                    fresh = true;
-                    s = 0;
+                    if (redo) start = true;
+                    else {
+                        const size_t pix = (size_t)(pxy >> 16) * cam.width + (pxy & 0xffffu);
+                        P.ids[pix] = id;
+                        P.ts[pix] = tv.best_t;
+                        have = false;
+                        fresh = true;
+                        s = 0;
+                    }
                 } else if (tv.best_rank == RT_MISS_RANK) {         // miss: environment light is vec3(0) (:279-282)
                     fresh = true;
                 } else {
-                    if (STATS) cnt.hits++;
                     // ---- rebuild the HitInfo of the winner ----
                     const float best_t = tv.best_t;
                     const v3 hit_point = madd3(org, best_t, dir);
@@ -498,15 +570,18 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         const float v = 1.0f - u - w;
                         const float4* nn = PS.tri_nrm + 3 * (size_t)slot;
                         const float4 na = nn[0], nb = nn[1], nc = nn[2];
+                        // loaded together with the triangle's records, so the check adds no memory round trip
+                        if (SAH && !gated) redo = !ref_leaf_box_passes(PS, slot, org, inv) || P.recheck_all != 0;
                         normal = V3(na.x * u + nb.x * v + nc.x * w, na.y * u + nb.y * v + nc.y * w,
                                     na.z * u + nb.z * v + nc.z * w);
                         hit_id = __float_as_int(g3.z);
                         hit_mat = __float_as_int(na.w);
                     }
+                    if (STATS) cnt.hits += !redo;
                     const MatDev* m = material_of(PS, hit_mat);
                     const float alpha = m->color[3];
-                    bool ended = false, passthrough = false;
-                    if (alpha < 0.99999f) {                        // :725-736
+                    bool ended = false, passthrough = redo;   // a query to be repeated changes nothing here
+                    if (!redo && alpha < 0.99999f) {                        // :725-736
                         if (random_value(rng) > alpha) {
                             passthrough = true;
                             if (bounce == P.max_bounces) ended = true;
@@ -573,7 +648,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         }
                     }
                     if (ended) fresh = true;
-                    else { bounce++; start = true; }
+                    else { bounce += !redo; start = true; }
                 }
                 if (fresh && !FIRST_HIT) {                         // the path is over (:989): totalIncomingLight += inc
                     // the sample's running sum lives in the radiance buffer (three fewer live registers);
@@ -640,7 +715,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 }
             }
             if (start) {                                           // begin one closest-hit query (:518-541)
-                if (STATS) cnt.rays++;
+                if (STATS) cnt.rays += !redo;
+                gated = redo;
                 inv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
                 tv.best_t = 1e20f;
                 tv.best_rank = RT_MISS_RANK;
@@ -671,7 +747,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     tv.node_live = true;
                 } else {
                     tv.cur = RT_NONE;
-                    tv.mask = root_mask<STATS, CULL>(__builtin_amdgcn_readfirstlane(PS.n_meshes), s_roots, org, inv, tv.best_t, cnt);
+                    tv.mask = root_mask<STATS, CULL>(__builtin_amdgcn_readfirstlane(PS.n_meshes), s_roots, org, inv, tv.best_t, sah, cnt);
                     tv.node_live = tv.mask != 0;
                 }
                 mode = M_TRAV;

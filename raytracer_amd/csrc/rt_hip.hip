@@ -133,14 +133,48 @@ __global__ __launch_bounds__(256) void k_refit_level(const VNode* vn, const int*
 // interior record r <- boxes of its children; PackInfo is static topology
 struct PackInfo { int c1, c2, ref1, ref2; };
 
+// SAH structure: each box carries the slack of its widened slab test (rt_dev_trace.h,
+// sah_widened_hit): e2 = 2 * (2^-16 of its largest coordinate + 2^-20).  0 for the reference's
+// structure, whose tests are the reference's own.
+__device__ __forceinline__ float box_slack(float4 lo, float4 hi, int sah) {
+    if (!sah) return 0.0f;
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
+    return 2.0f * (m * 0x1p-16f + 0x1p-20f);
+}
+
+// one thread per leaf of the REFERENCE's tree: box of its (posed) triangles, written to every member slot
+__global__ __launch_bounds__(256) void k_ref_leaf_boxes(const int* leaf_off, const int* leaf_slots, int n_leaves, const float4* geo,
+                                                        float4* tri_box) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int q = leaf_off[i]; q < leaf_off[i + 1]; q++) {
+        const int k = leaf_slots[q];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float4 p = geo[4 * (size_t)k + c];
+            lo[0] = p.x < lo[0] ? p.x : lo[0]; hi[0] = p.x > hi[0] ? p.x : hi[0];
+            lo[1] = p.y < lo[1] ? p.y : lo[1]; hi[1] = p.y > hi[1] ? p.y : hi[1];
+            lo[2] = p.z < lo[2] ? p.z : lo[2]; hi[2] = p.z > hi[2] ? p.z : hi[2];
+        }
+    }
+    for (int q = leaf_off[i]; q < leaf_off[i + 1]; q++) {
+        const int k = leaf_slots[q];
+        tri_box[2 * (size_t)k] = make_float4(lo[0], lo[1], lo[2], 0.f);
+        tri_box[2 * (size_t)k + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pack_nodes(const PackInfo* pi, int n_rec, const float4* nbox, float4* nodes,
-                                                    const int* root_v, const int* root_ref, int n_meshes, float4* roots) {
+                                                    const int* root_v, const int* root_ref, int n_meshes, float4* roots, int pad) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_rec) {
         PackInfo p = pi[i];
         float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 lo1 = p.c1 >= 0 ? nbox[2 * (size_t)p.c1] : z, hi1 = p.c1 >= 0 ? nbox[2 * (size_t)p.c1 + 1] : z;
         float4 lo2 = p.c2 >= 0 ? nbox[2 * (size_t)p.c2] : z, hi2 = p.c2 >= 0 ? nbox[2 * (size_t)p.c2 + 1] : z;
+        lo2.w = box_slack(lo1, hi1, pad && p.c1 >= 0);
+        hi2.w = box_slack(lo2, hi2, pad && p.c2 >= 0);
         lo1.w = __int_as_float(p.ref1);
         hi1.w = __int_as_float(p.ref2);
         float4* o = nodes + 4 * (size_t)i;
@@ -148,6 +182,7 @@ __global__ __launch_bounds__(256) void k_pack_nodes(const PackInfo* pi, int n_re
     }
     if (i < n_meshes) {
         float4 lo = nbox[2 * (size_t)root_v[i]], hi = nbox[2 * (size_t)root_v[i] + 1];
+        hi.w = box_slack(lo, hi, pad);
         lo.w = __int_as_float(root_ref[i]);
         roots[2 * i] = lo;
         roots[2 * i + 1] = hi;
@@ -196,10 +231,10 @@ __global__ __launch_bounds__(256) void k_accumulate(const float* totals, float* 
 #ifndef RT_WAVES
 #define RT_WAVES 5
 #endif
-template <bool STATS, bool CULL, bool FIRST_HIT>
+template <bool STATS, bool CULL, bool FIRST_HIT, bool SAH>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES) void k_trace(TraceArgs a) {
     extern __shared__ float4 s_mem[];
-    trace_pixels<STATS, CULL, FIRST_HIT>(a, s_mem);
+    trace_pixels<STATS, CULL, FIRST_HIT, SAH>(a, s_mem);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -237,7 +272,9 @@ struct rt_ctx {
     hipStream_t own_stream = nullptr;   // created by rt_create
     char err[512] = {0};
     // scene (device)
-    DevBuf<float4> rest, geo, nrm, nodes, roots, nbox;
+    DevBuf<float4> rest, geo, nrm, nodes, roots, nbox, tri_box;
+    DevBuf<int> ref_leaf_off, ref_leaf_slots;   // RT_ACCEL_SAH: the reference's leaves as lists of our slots
+    int n_ref_leaves = 0;
     DevBuf<int> slot_mesh, slot_rem, slot_id, slot_rank, rank_slot, level_nodes, root_v, root_ref;
     DevBuf<float> xf;
     DevBuf<unsigned char> dirty;
@@ -249,8 +286,8 @@ struct rt_ctx {
     DevBuf<unsigned int> work_counter;
     DevBuf<float> totals;                 // per-(pass, pixel) radiance of one trace launch (grow-only)
     int n_cus = 0;
-    int blocks_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per k_trace variant, for the LDS size in lds_for
-    size_t lds_for[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int blocks_per_cu[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // per k_trace variant, for the LDS size in lds_for
+    size_t lds_for[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // scene (host mirrors)
     std::vector<float> h_xf;
     std::vector<unsigned char> h_dirty;
@@ -270,6 +307,7 @@ struct rt_ctx {
     bool cull = false;                    // conservative distance culling (rt_set_cull)
     int node_bias = 0;
     int burst8 = 4;
+    int recheck_all = 0;                  // RT_SAH_RECHECK_ALL: run the SAH structure's repeat path on every query (tests)
     int refill_below = 0;                 // lanes still traversing below which a wave shades/refills; 0 = measured default
     // camera / image
     DevCamera cam{};
@@ -344,6 +382,9 @@ int run_prep(rt_ctx* c) {
     if (c->flags_pending && c->n_slots)
         hipLaunchKernelGGL(k_tri_flags, dim3(blocks_for(c->n_slots)), dim3(256), 0, c->stream, c->slot_mesh.p, c->mats.p, c->geo.p, c->n_slots);
     c->flags_pending = false;
+    if (c->scene_is_sah && c->n_ref_leaves)
+        hipLaunchKernelGGL(k_ref_leaf_boxes, dim3(blocks_for(c->n_ref_leaves)), dim3(256), 0, c->stream, c->ref_leaf_off.p,
+                           c->ref_leaf_slots.p, c->n_ref_leaves, c->geo.p, c->tri_box.p);
     for (int l = (int)c->level_off.size() - 2; l >= 0; l--) {
         int n = c->level_off[l + 1] - c->level_off[l];
         if (n <= 0) continue;
@@ -353,7 +394,7 @@ int run_prep(rt_ctx* c) {
     size_t m = (size_t)std::max(c->n_rec, c->n_meshes);
     if (m)
         hipLaunchKernelGGL(k_pack_nodes, dim3(blocks_for(m)), dim3(256), 0, c->stream, c->pack.p, c->n_rec, c->nbox.p,
-                           c->nodes.p, c->root_v.p, c->root_ref.p, c->n_meshes, c->roots.p);
+                           c->nodes.p, c->root_v.p, c->root_ref.p, c->n_meshes, c->roots.p, c->scene_is_sah ? 1 : 0);
     HIPCK(c, hipGetLastError());
     for (auto& d : c->h_dirty) d = 0;
     c->prep_pending = false;
@@ -363,7 +404,7 @@ int run_prep(rt_ctx* c) {
 DevScene scene_view(const rt_ctx* c) {
     DevScene s;
     s.tri_geo = c->geo.p; s.tri_nrm = c->nrm.p; s.nodes = c->nodes.p; s.roots = c->roots.p;
-    s.mats = c->mats.p; s.spheres = c->spheres.p; s.rank_slot = c->rank_slot.p; s.slot_id = c->slot_id.p; s.n_meshes = c->n_meshes; s.n_spheres = c->n_spheres;
+    s.mats = c->mats.p; s.spheres = c->spheres.p; s.rank_slot = c->rank_slot.p; s.slot_id = c->slot_id.p; s.tri_box = c->scene_is_sah ? c->tri_box.p : nullptr; s.n_meshes = c->n_meshes; s.n_spheres = c->n_spheres;
     s.stack_depth = c->stack_depth;
     s.tlas_root = c->tlas_root;
     return s;
@@ -384,16 +425,17 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.n_chunks = 0;
     a.node_bias = c->node_bias;
     a.burst8 = c->burst8;
+    a.recheck_all = c->recheck_all;
     a.refill_below = c->refill_below > 0 ? c->refill_below : (c->cull ? 28 : 32);   // best measured, DESIGN.md 5
 }
 
-template <bool STATS, bool CULL, bool FIRST>
+template <bool STATS, bool CULL, bool FIRST, bool SAH>
 int launch_one(rt_ctx* c, const TraceArgs& a, int key) {
     // dynamic LDS: root table + per-lane node stack and leaf queue (+ the entry-distance plane when culling)
     const size_t lds = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_meshes) + RT_PC_F4) * sizeof(float4) + (size_t)(c->stack_depth + RT_LQ) * RT_BLOCK * (CULL ? 6 : 4);
     if (c->lds_for[key] != lds || c->blocks_per_cu[key] <= 0) {
         int nb = 0;
-        HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST>, RT_BLOCK, lds));
+        HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH>, RT_BLOCK, lds));
         if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (BVH depth %d)", lds, c->stack_depth - 1);
         c->blocks_per_cu[key] = nb;
         c->lds_for[key] = lds;
@@ -401,21 +443,29 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key) {
     // every wave takes whole chunks: no point in more waves than chunks
     const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_chunks + 3) / 4);
     HIPCK(c, hipMemsetAsync(c->work_counter.p, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST>), dim3(std::max(grid, 1u)), dim3(RT_BLOCK), lds, c->stream, a);
+    hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST, SAH>), dim3(std::max(grid, 1u)), dim3(RT_BLOCK), lds, c->stream, a);
     return RT_OK;
 }
 
 int launch_trace(rt_ctx* c, const TraceArgs& a, bool first_hit) {
-    const int key = (c->stats_on ? 4 : 0) | (c->cull ? 2 : 0) | (first_hit ? 1 : 0);
+    const int key = (c->scene_is_sah ? 8 : 0) | (c->stats_on ? 4 : 0) | (c->cull ? 2 : 0) | (first_hit ? 1 : 0);
     switch (key) {
-    case 0: return launch_one<false, false, false>(c, a, key);
-    case 1: return launch_one<false, false, true>(c, a, key);
-    case 2: return launch_one<false, true, false>(c, a, key);
-    case 3: return launch_one<false, true, true>(c, a, key);
-    case 4: return launch_one<true, false, false>(c, a, key);
-    case 5: return launch_one<true, false, true>(c, a, key);
-    case 6: return launch_one<true, true, false>(c, a, key);
-    default: return launch_one<true, true, true>(c, a, key);
+    case 0: return launch_one<false, false, false, false>(c, a, key);
+    case 1: return launch_one<false, false, true, false>(c, a, key);
+    case 2: return launch_one<false, true, false, false>(c, a, key);
+    case 3: return launch_one<false, true, true, false>(c, a, key);
+    case 4: return launch_one<true, false, false, false>(c, a, key);
+    case 5: return launch_one<true, false, true, false>(c, a, key);
+    case 6: return launch_one<true, true, false, false>(c, a, key);
+    case 7: return launch_one<true, true, true, false>(c, a, key);
+    case 8: return launch_one<false, false, false, true>(c, a, key);
+    case 9: return launch_one<false, false, true, true>(c, a, key);
+    case 10: return launch_one<false, true, false, true>(c, a, key);
+    case 11: return launch_one<false, true, true, true>(c, a, key);
+    case 12: return launch_one<true, false, false, true>(c, a, key);
+    case 13: return launch_one<true, false, true, true>(c, a, key);
+    case 14: return launch_one<true, true, false, true>(c, a, key);
+    default: return launch_one<true, true, true, true>(c, a, key);
     }
 }
 
@@ -477,6 +527,7 @@ int rt_create(int device, rt_ctx** out) {
     if (const char* e = getenv("RT_TLAS_ABOVE")) c->tlas_above = std::max(1, std::min(32, atoi(e)));
     if (const char* e = getenv("RT_NODE_BIAS")) c->node_bias = atoi(e);
     if (const char* e = getenv("RT_BURST8")) c->burst8 = std::max(0, std::min(64, atoi(e)));
+    if (const char* e = getenv("RT_SAH_RECHECK_ALL")) c->recheck_all = atoi(e) != 0;
     if (const char* e = getenv("RT_REFILL_BELOW")) c->refill_below = std::max(1, std::min(64, atoi(e)));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
@@ -493,7 +544,7 @@ int rt_create(int device, rt_ctx** out) {
 
 static void free_scene(rt_ctx* c) {
     c->rest.release(); c->geo.release(); c->nrm.release(); c->nodes.release(); c->roots.release(); c->nbox.release();
-    c->slot_mesh.release(); c->slot_rem.release(); c->slot_id.release(); c->slot_rank.release(); c->rank_slot.release(); c->level_nodes.release();
+    c->slot_mesh.release(); c->slot_rem.release(); c->slot_id.release(); c->slot_rank.release(); c->rank_slot.release(); c->tri_box.release(); c->ref_leaf_off.release(); c->ref_leaf_slots.release(); c->level_nodes.release();
     c->root_v.release(); c->root_ref.release(); c->xf.release(); c->dirty.release(); c->vnodes.release();
     c->pack.release(); c->mats.release(); c->spheres.release();
     c->have_scene = false;
@@ -627,6 +678,10 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     std::vector<int> slot_rank(slot_id.size()), rank_slot(slot_id.size());
     for (size_t k = 0; k < slot_id.size(); k++) slot_rank[k] = rank_slot[k] = (int)k;
     const std::vector<int> ref_first_visit = first_visit;
+    // the reference's leaves as (start, count) ranges of reference ranks, for the SAH structure's candidate gate
+    std::vector<std::pair<int, int>> ref_leaves;
+    for (const VNode& vn : vnodes)
+        if (vn.c1 < 0 && vn.c2 < 0 && vn.count > 0) ref_leaves.push_back({vn.start, vn.count});
     const bool sah = c->accel == RT_ACCEL_SAH && !slot_id.empty();
     if (sah) {
         // ---- opt-in performance structure: a binned-SAH tree per mesh over the same triangles ----
@@ -671,6 +726,14 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
         for (size_t k = 0; k < slot_id.size(); k++) {
             slot_rank[k] = rank_of_tri[slot_id[k]];
             rank_slot[slot_rank[k]] = (int)k;
+        }
+    }
+    std::vector<int> ref_leaf_off, ref_leaf_slots;
+    if (sah) {
+        ref_leaf_off.push_back(0);
+        for (auto& lf : ref_leaves) {
+            for (int r = lf.first; r < lf.first + lf.second; r++) ref_leaf_slots.push_back(rank_slot[r]);
+            ref_leaf_off.push_back((int)ref_leaf_slots.size());
         }
     }
     first_visit = ref_first_visit;          // rt_read_nodes48 maps the REFERENCE's nodes (unavailable with RT_ACCEL_SAH)
@@ -759,6 +822,10 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     if ((rc = upload(c, c->slot_id, slot_id))) return rc;
     if ((rc = upload(c, c->slot_rank, slot_rank))) return rc;
     if ((rc = upload(c, c->rank_slot, rank_slot))) return rc;
+    if ((rc = upload(c, c->ref_leaf_off, ref_leaf_off))) return rc;
+    if ((rc = upload(c, c->ref_leaf_slots, ref_leaf_slots))) return rc;
+    c->n_ref_leaves = sah ? (int)ref_leaves.size() : 0;
+    if (sah) HIPCK(c, c->tri_box.alloc(2 * (size_t)slot_id.size()));
     if ((rc = upload(c, c->vnodes, vnodes))) return rc;
     if ((rc = upload(c, c->pack, pack))) return rc;
     if ((rc = upload(c, c->level_nodes, level_nodes))) return rc;
