@@ -159,7 +159,10 @@ def main() -> None:
     pmc = ROOT / "profiles" / "pmc_latest.json"
     if pmc.exists():
         try:
-            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            rec = json.loads(pmc.read_text())
+            # the counters were collected on the default mode's kernel: no figure for the others
+            if not args.strict and not args.reference_structure:
+                traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -220,7 +223,7 @@ def main() -> None:
             "roofline": {
                 "bound": "mfma",
                 "engine": "f32 VALU (no GEMM shape on this path; the f32 vector-FMA peak equals the dense f32 MFMA peak)",
-                "kernel": "k_trace<STATS=false,CULL=%s,FIRST_HIT=false>" % ("false" if args.strict else "true"),
+                "kernel": "k_trace<STATS=false,CULL=%s,FIRST_HIT=false,SAH=%s>" % ("false" if args.strict else "true", "false" if args.reference_structure else "true"),
                 "achieved": round(achieved_tflops, 3),
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
