@@ -1,8 +1,8 @@
 """Entry point with the reference's shape (run.py:1-10): pick a scene module, start the app.
 
-    python run.py [--frames N] [--height H] [--passes P] [--bounces B] [--cull]
+    python run.py [--scene suzanne|dragon|dragon_animated] [--frames N] [--height H] [--passes P] [--bounces B] [--cull]
 
-Headless: renders N animation frames of the Suzanne scene on GPU 0 and writes PNG + float32
+Headless: renders N animation frames of the chosen scene module on GPU 0 and writes PNG + float32
 dumps under renders/RayTracerDynamic/<timestamp>/ at the reference's cadence."""
 import argparse
 
@@ -10,6 +10,8 @@ import raytracer_amd.scripts.application as application
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", choices=("suzanne", "dragon", "dragon_animated"), default="suzanne",
+                    help="scene module: final_scene_numba, dragon_scene or dragon_scene_animated")
     ap.add_argument("--frames", type=int, default=1)
     ap.add_argument("--height", type=int, default=1080 // 4)
     ap.add_argument("--passes", type=int, default=None, help="override the scene's passes_per_frame")
@@ -18,9 +20,12 @@ if __name__ == "__main__":
     args = ap.parse_args()
 
     from raytracer_amd.scripts.animate import FrameAnimation
-    from raytracer_amd.scripts.scenes import final_scene_numba
+    import importlib
 
-    application.set_scene(final_scene_numba)
+    module = {"suzanne": "final_scene_numba", "dragon": "dragon_scene", "dragon_animated": "dragon_scene_animated"}[args.scene]
+    scene_module = importlib.import_module("raytracer_amd.scripts.scenes." + module)
+
+    application.set_scene(scene_module)
     application.HEADLESS = True
     if args.passes is not None or args.bounces is not None:
         def override(cam, i):
@@ -28,7 +33,7 @@ if __name__ == "__main__":
                 cam.passes_per_frame = args.passes
             if args.bounces is not None:
                 cam.bounces_per_ray = args.bounces
-        final_scene_numba.scene.animations.append(FrameAnimation(final_scene_numba.scene.cam, override))
+        scene_module.scene.animations.append(FrameAnimation(scene_module.scene.cam, override))
     prog = None
     if args.cull:
         app0 = application.Application.__new__(application.Application)
