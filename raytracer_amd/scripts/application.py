@@ -199,11 +199,13 @@ class RayTracerDynamic(ProgramABC):
 
     def __init__(self, app: Application, file_vertex_shader: str, file_fragment_shader: str, width: int, height: int,
                  standalone=not HEADLESS, require=460, lib: ffi.RtLib | None = None, device: int = 0,
-                 save_frames: bool = True, export_root: str | Path = "renders/RayTracerDynamic", cull: bool = False) -> None:
+                 save_frames: bool = True, export_root: str | Path = "renders/RayTracerDynamic", cull: bool = False,
+                 sah: bool = False) -> None:
         self._lib = lib                       # tests inject a checker library; the product loads the HIP one
         self._device = device
         self.save_frames = save_frames
         self.cull = cull                      # distance culling: same image, fewer box tests
+        self.sah = sah                        # traverse the library's SAH tree over the same triangles: same image
         self.export_root = Path(export_root)
         self.MAX_RAY_BOUNCES = 8
         self.RAYS_PER_PIXEL = 32
@@ -219,6 +221,7 @@ class RayTracerDynamic(ProgramABC):
             self.ctx.close()
         self.ctx = self._lib.create(self._device)
         self.ctx.set_cull(self.cull)
+        self.ctx.set_accel(self.sah)
         self._scene_uploaded = None
 
     # -- application.py:849-915 ---------------------------------------------------------------

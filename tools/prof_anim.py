@@ -2,7 +2,8 @@
 """BASELINE.json configs[2]: the keyframe animation of the Suzanne room through the Application /
 RayTracerDynamic mirror - per frame: animate hooks (host), pose + material + camera updates over
 the C-ABI, device pose/refit, 64 passes at 1080p, read-back of the mean.  Prints s/frame.
-usage: python tools/prof_anim.py [frames] [height] [passes] [bounces]"""
+usage: python tools/prof_anim.py [frames] [height] [passes] [bounces]   (RT_SAH=1: the SAH structure)"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -29,7 +30,7 @@ A.HEADLESS = True
 app = A.Application.__new__(A.Application)
 prog = A.RayTracerDynamic.__new__(A.RayTracerDynamic)
 A.RayTracerDynamic.__init__(prog, app, file_vertex_shader="shaders/raytracer.vs.glsl", file_fragment_shader="shaders/raytracer.fs.glsl",
-                            width=height * 16 // 9, height=height, save_frames=False, cull=True)
+                            width=height * 16 // 9, height=height, save_frames=False, cull=True, sah=os.environ.get('RT_SAH', '0') == '1')
 A.Application.__init__(app, render_height=height, max_frames=frames + 1, program=prog)
 t = []
 orig = prog.calculate_frame
