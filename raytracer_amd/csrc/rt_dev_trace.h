@@ -86,7 +86,7 @@ struct DevScene {
     const float4* tri_box; // RT_ACCEL_SAH only: 2 x float4 per slot = the box of the triangle's leaf in the REFERENCE's tree
     int n_meshes;
     int n_spheres;
-    int stack_depth;      // stack entries a lane can need (max tree depth + 1)
+    int stack_depth;      // node stack entries a lane has in LDS (rt_hip.hip sizes it for full occupancy); DEEP builds: deeper entries go to stack_ovf
     int tlas_root;        // > 32 meshes: record of the top-level tree over the mesh roots; else -1 (roots in LDS)
 };
 
@@ -205,6 +205,7 @@ enum { M_TRAV = 0, M_PATH = 2, M_DONE = 3 };
 #ifndef RT_LQ
 #define RT_LQ 2
 #endif
+#define RT_MIN_STACK_LDS 4         // node stack entries a lane always has in LDS
 #define RT_TFB_BIT 0x40000000      // tri_geo[3].w = mesh index | RT_TFB_BIT if the mesh is transparentFromBehind
 
 struct TraceArgs {
@@ -217,6 +218,8 @@ struct TraceArgs {
     unsigned long long* counters; // 4
     float* totals;                // n_passes x W*H x 3: per-(pass, pixel) radiance, folded by k_accumulate
     unsigned int* work_counter;   // next chunk to hand out (zeroed before the launch)
+    int2* stack_ovf;              // node stack entries beyond the LDS ones: entry e of launch lane g at [(e - stack_depth) * ovf_lanes + g]
+    uint32_t ovf_lanes;           // lanes of the launch (grid x 256)
     uint32_t n_chunks, n_bx, n_by;   // chunks = n_passes x n_by x n_bx blocks of 16x16 pixels
     uint32_t first_pass, n_passes, pass_stride;
     int rays_per_pixel, max_bounces, sum_mode;
@@ -308,7 +311,7 @@ __device__ __forceinline__ bool ref_leaf_box_passes(const DevScene& S, int slot,
     return box_test(org, inv, rb[0], rb[1], ta, tb);
 }
 
-template <bool STATS, bool CULL, bool FIRST_HIT, bool SAH>
+template <bool STATS, bool CULL, bool FIRST_HIT, bool SAH, bool DEEP>
 __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) {
     const DevScene& S = a.scene;
     // ---- LDS: mesh root table (2 float4 per mesh), then the per-lane columns
@@ -385,8 +388,17 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         // ---- take up node work: a deferred far child, else the next mesh root ----
                         if (tv.sp > 0) {
                             tv.sp--;
-                            int c = s_stack[tv.sp * RT_BLOCK];
-                            if (CULL && unpack_dist(s_stack_t[tv.sp * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS)
+                            int c;
+                            float tc;
+                            if (!DEEP || tv.sp < S.stack_depth) {
+                                c = s_stack[tv.sp * RT_BLOCK];
+                                tc = CULL ? unpack_dist(s_stack_t[tv.sp * RT_BLOCK]) : 0.0f;
+                            } else {                                // a rare deep entry (see stack_ovf)
+                                const int2 e = a.stack_ovf[(size_t)(tv.sp - S.stack_depth) * a.ovf_lanes + (blockIdx.x * RT_BLOCK + threadIdx.x)];
+                                c = e.x;
+                                tc = __int_as_float(e.y);
+                            }
+                            if (CULL && tc > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS)
                                 c = RT_NONE;
                             tv.cur = c;
                         } else if (tv.mask) {
@@ -445,8 +457,14 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         }
                         const bool in_n = hn && rn >= 0, in_f = hf && rf >= 0;
                         if (in_n && in_f) {
-                            s_stack[tv.sp * RT_BLOCK] = rf;
-                            if (CULL) s_stack_t[tv.sp * RT_BLOCK] = pack_dist(tf);
+                            if (!DEEP || tv.sp < S.stack_depth) {
+                                s_stack[tv.sp * RT_BLOCK] = rf;
+                                if (CULL) s_stack_t[tv.sp * RT_BLOCK] = pack_dist(tf);
+                            } else {
+                                // the distance is kept as the LDS entries keep it, so where an entry lives changes nothing
+                                a.stack_ovf[(size_t)(tv.sp - S.stack_depth) * a.ovf_lanes + (blockIdx.x * RT_BLOCK + threadIdx.x)] =
+                                    make_int2(rf, __float_as_int(unpack_dist(pack_dist(tf))));
+                            }
                             tv.sp++;
                         }
                         tv.cur = in_n ? rn : (in_f ? rf : RT_NONE);

@@ -231,10 +231,10 @@ __global__ __launch_bounds__(256) void k_accumulate(const float* totals, float* 
 #ifndef RT_WAVES
 #define RT_WAVES 5
 #endif
-template <bool STATS, bool CULL, bool FIRST_HIT, bool SAH>
+template <bool STATS, bool CULL, bool FIRST_HIT, bool SAH, bool DEEP>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES) void k_trace(TraceArgs a) {
     extern __shared__ float4 s_mem[];
-    trace_pixels<STATS, CULL, FIRST_HIT, SAH>(a, s_mem);
+    trace_pixels<STATS, CULL, FIRST_HIT, SAH, DEEP>(a, s_mem);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -286,8 +286,12 @@ struct rt_ctx {
     DevBuf<unsigned int> work_counter;
     DevBuf<float> totals;                 // per-(pass, pixel) radiance of one trace launch (grow-only)
     int n_cus = 0;
-    int blocks_per_cu[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // per k_trace variant, for the LDS size in lds_for
-    size_t lds_for[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t lds_per_cu = 160 * 1024;
+    int stack_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // per k_trace variant: node stack entries in LDS for the scene in place
+    DevBuf<int2> stack_ovf;               // deeper entries (rare): (stack_depth - cap) x launch lanes
+    size_t stack_ovf_n = 0;
+    int stack_lds_force = 0;              // RT_STACK_LDS: LDS node stack entries, whatever the occupancy (tests of the deep-entry path)
+    int blocks_per_cu[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // per k_trace variant, for the scene in place (0 = not yet asked)
     // scene (host mirrors)
     std::vector<float> h_xf;
     std::vector<unsigned char> h_dirty;
@@ -429,43 +433,86 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.refill_below = c->refill_below > 0 ? c->refill_below : (c->cull ? 28 : 32);   // best measured, DESIGN.md 5
 }
 
-template <bool STATS, bool CULL, bool FIRST, bool SAH>
-int launch_one(rt_ctx* c, const TraceArgs& a, int key) {
-    // dynamic LDS: root table + per-lane node stack and leaf queue (+ the entry-distance plane when culling)
-    const size_t lds = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_meshes) + RT_PC_F4) * sizeof(float4) + (size_t)(c->stack_depth + RT_LQ) * RT_BLOCK * (CULL ? 6 : 4);
-    if (c->lds_for[key] != lds || c->blocks_per_cu[key] <= 0) {
-        int nb = 0;
-        HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH>, RT_BLOCK, lds));
-        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (BVH depth %d)", lds, c->stack_depth - 1);
+// dynamic LDS of a k_trace launch: root table + kernel-argument copy + per-lane node stack and leaf
+// queue (+ the entry-distance plane when culling).  The node stack of a deep tree (dragon scene:
+// 29 levels with the top-level tree = 48 KB per workgroup) would leave 3 workgroups per CU, so
+// only as many entries as keep RT_WAVES workgroups resident live in LDS; the rare deeper ones go
+// to `stack_ovf` in global memory (DEEP instantiations; a scene whose whole stack fits runs the
+// instantiation without that test).
+template <bool STATS, bool CULL, bool FIRST, bool SAH, bool DEEP>
+int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
+    const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_meshes) + RT_PC_F4) * sizeof(float4);
+    const size_t per_ent = (size_t)RT_BLOCK * (CULL ? 6 : 4);
+    if (c->blocks_per_cu[key] <= 0) {
+        int nb = 0, nb_best = 0;
+        for (;;) {
+            HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, fixed + (size_t)(cap + RT_LQ) * per_ent));
+            if (!DEEP || nb >= RT_WAVES || cap <= RT_MIN_STACK_LDS || c->stack_lds_force > 0) break;
+            // lds_stack_entries guessed the allocation granule wrong, or registers are the limit
+            if (nb_best == 0)
+                HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_best, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, fixed + (size_t)(RT_MIN_STACK_LDS + RT_LQ) * per_ent));
+            if (nb >= nb_best) break;
+            cap--;
+        }
+        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (%d mesh roots)", fixed + (size_t)(cap + RT_LQ) * per_ent, c->n_meshes);
         c->blocks_per_cu[key] = nb;
-        c->lds_for[key] = lds;
+        c->stack_lds[key] = cap;
+        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] k_trace variant %d: %d of %d node stack entries in LDS, %zu bytes of LDS, %d workgroups per CU\n", key, cap, c->stack_depth, fixed + (size_t)(cap + RT_LQ) * per_ent, nb);
     }
+    cap = c->stack_lds[key];
+    const size_t lds = fixed + (size_t)(cap + RT_LQ) * per_ent;
     // every wave takes whole chunks: no point in more waves than chunks
-    const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_chunks + 3) / 4);
+    const unsigned grid = std::max(1u, (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_chunks + 3) / 4));
+    TraceArgs b = a;
+    b.scene.stack_depth = cap;
+    b.ovf_lanes = grid * RT_BLOCK;
+    const size_t need_ovf = (size_t)std::max(0, c->stack_depth - cap) * b.ovf_lanes;
+    if (c->stack_ovf_n < need_ovf) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        c->stack_ovf.release();
+        c->stack_ovf_n = 0;
+        HIPCK(c, c->stack_ovf.alloc(need_ovf));
+        c->stack_ovf_n = need_ovf;
+    }
+    b.stack_ovf = c->stack_ovf.p;
     HIPCK(c, hipMemsetAsync(c->work_counter.p, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST, SAH>), dim3(std::max(grid, 1u)), dim3(RT_BLOCK), lds, c->stream, a);
+    hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST, SAH, DEEP>), dim3(grid), dim3(RT_BLOCK), lds, c->stream, b);
     return RT_OK;
 }
 
+// node stack entries kept in LDS: all of them if RT_WAVES workgroups per CU still fit, else as many as do
+int lds_stack_entries(const rt_ctx* c) {
+    if (c->stack_lds_force > 0) return std::min(c->stack_depth, c->stack_lds_force);
+    const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_meshes) + RT_PC_F4) * sizeof(float4);
+    const size_t per_ent = (size_t)RT_BLOCK * (c->cull ? 6 : 4);
+    // LDS is handed out in 1280-byte granules on gfx950 (160 KB / 128): budget per workgroup rounded down to that
+    const size_t budget = (c->lds_per_cu / RT_WAVES) / 1280 * 1280;
+    if (fixed + (size_t)(c->stack_depth + RT_LQ) * per_ent <= budget) return c->stack_depth;
+    const int fit = (int)((budget > fixed ? budget - fixed : 0) / per_ent) - RT_LQ;
+    return std::max(RT_MIN_STACK_LDS, std::min(c->stack_depth, fit));
+}
+
+template <bool STATS, bool CULL, bool FIRST>
+int launch_accel(rt_ctx* c, const TraceArgs& a, int key, int cap) {
+    const bool deep = cap < c->stack_depth;
+    if (c->scene_is_sah) return deep ? launch_one<STATS, CULL, FIRST, true, true>(c, a, key, cap) : launch_one<STATS, CULL, FIRST, true, false>(c, a, key, cap);
+    return deep ? launch_one<STATS, CULL, FIRST, false, true>(c, a, key, cap) : launch_one<STATS, CULL, FIRST, false, false>(c, a, key, cap);
+}
+
 int launch_trace(rt_ctx* c, const TraceArgs& a, bool first_hit) {
-    const int key = (c->scene_is_sah ? 8 : 0) | (c->stats_on ? 4 : 0) | (c->cull ? 2 : 0) | (first_hit ? 1 : 0);
+    // the instantiation is fixed by (stats, cull, first hit) and, per scene, by (structure, deep):
+    // 8 cache slots for the occupancy of the scene in place
+    const int key = (c->stats_on ? 4 : 0) | (c->cull ? 2 : 0) | (first_hit ? 1 : 0);
+    const int cap = lds_stack_entries(c);
     switch (key) {
-    case 0: return launch_one<false, false, false, false>(c, a, key);
-    case 1: return launch_one<false, false, true, false>(c, a, key);
-    case 2: return launch_one<false, true, false, false>(c, a, key);
-    case 3: return launch_one<false, true, true, false>(c, a, key);
-    case 4: return launch_one<true, false, false, false>(c, a, key);
-    case 5: return launch_one<true, false, true, false>(c, a, key);
-    case 6: return launch_one<true, true, false, false>(c, a, key);
-    case 7: return launch_one<true, true, true, false>(c, a, key);
-    case 8: return launch_one<false, false, false, true>(c, a, key);
-    case 9: return launch_one<false, false, true, true>(c, a, key);
-    case 10: return launch_one<false, true, false, true>(c, a, key);
-    case 11: return launch_one<false, true, true, true>(c, a, key);
-    case 12: return launch_one<true, false, false, true>(c, a, key);
-    case 13: return launch_one<true, false, true, true>(c, a, key);
-    case 14: return launch_one<true, true, false, true>(c, a, key);
-    default: return launch_one<true, true, true, true>(c, a, key);
+    case 0: return launch_accel<false, false, false>(c, a, key, cap);
+    case 1: return launch_accel<false, false, true>(c, a, key, cap);
+    case 2: return launch_accel<false, true, false>(c, a, key, cap);
+    case 3: return launch_accel<false, true, true>(c, a, key, cap);
+    case 4: return launch_accel<true, false, false>(c, a, key, cap);
+    case 5: return launch_accel<true, false, true>(c, a, key, cap);
+    case 6: return launch_accel<true, true, false>(c, a, key, cap);
+    default: return launch_accel<true, true, true>(c, a, key, cap);
     }
 }
 
@@ -528,9 +575,13 @@ int rt_create(int device, rt_ctx** out) {
     if (const char* e = getenv("RT_NODE_BIAS")) c->node_bias = atoi(e);
     if (const char* e = getenv("RT_BURST8")) c->burst8 = std::max(0, std::min(64, atoi(e)));
     if (const char* e = getenv("RT_SAH_RECHECK_ALL")) c->recheck_all = atoi(e) != 0;
+    if (const char* e = getenv("RT_STACK_LDS")) c->stack_lds_force = std::max(0, std::min(64, atoi(e)));
     if (const char* e = getenv("RT_REFILL_BELOW")) c->refill_below = std::max(1, std::min(64, atoi(e)));
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        c->n_cus = prop.multiProcessorCount;
+        if (prop.maxSharedMemoryPerMultiProcessor > 0) c->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+    }
     if (c->n_cus <= 0) c->n_cus = 256;
     if (c->work_counter.alloc(1) != hipSuccess || c->counters.alloc(16) != hipSuccess ||
         hipMemsetAsync(c->counters.p, 0, 128, c->stream) != hipSuccess) {
@@ -559,6 +610,7 @@ int rt_destroy(rt_ctx* c) {
     c->accum_own.release();
     c->totals.release();
     c->work_counter.release();
+    c->stack_ovf.release();
     c->counters.release();
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -849,6 +901,8 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     c->h_dirty.assign((size_t)std::max(n_meshes, 1), 2);        // 2 = copy rest pose as given
     c->level_off = level_off;
     c->stack_depth = max_depth + 1;
+    for (int k = 0; k < 16; k++) c->blocks_per_cu[k] = 0;   // LDS layout and occupancy are per scene
+    if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] scene: %d slots, %d records, max depth %d, %s\n", c->n_slots, c->n_rec, max_depth, sah ? "SAH" : "reference structure");
     c->tlas_root = tlas_root;
     c->scene_is_sah = sah;
     c->node_first_visit = first_visit;

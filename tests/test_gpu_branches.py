@@ -48,3 +48,35 @@ def test_pose_of_many_meshes_bit_exact(oracle_lib, hip_lib):
     g = make_ctx(hip_lib, stress_scene(spheres=False), 16, 9)
     assert np.array_equal(o.read_tris28().view(np.uint32), g.read_tris28().view(np.uint32))
     assert o.read_nodes48(NODE_DTYPE).tobytes() == g.read_nodes48(NODE_DTYPE).tobytes()
+
+
+@pytest.mark.gpu
+def test_deep_stack_entries_in_global_memory(hip_lib, monkeypatch):
+    """Only as many node stack entries as keep the CU full live in LDS; deeper ones go to global
+    memory.  RT_STACK_LDS (read at rt_create) forces the LDS part down to 1 and 2 entries, so that
+    most pushes take the deep path: same first hits, same image, same counters, in all modes."""
+    from conftest import build_suzanne, make_ctx
+
+    def run(sah, cull):
+        sc = build_suzanne(0)
+        c = hip_lib.create()
+        c.set_accel(sah)
+        c.load_scene(sc)
+        c.load_camera(sc.cam)
+        c.resize(160, 90)
+        c.set_cull(cull)
+        c.enable_stats(True)
+        ids, ts = c.first_hit(1)
+        c.render(1, 2, 1, 2, 4, 0)
+        return ids, ts, c.read_mean(), c.stats()
+
+    for sah, cull in ((False, False), (False, True), (True, True)):
+        a = run(sah, cull)
+        for n in (1, 2):
+            monkeypatch.setenv("RT_STACK_LDS", str(n))
+            b = run(sah, cull)
+            monkeypatch.delenv("RT_STACK_LDS")
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+            assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+            for k in ("rays", "box_tests", "tri_tests", "shaded_hits"):
+                assert a[3][k] == b[3][k], (sah, cull, n, k)
