@@ -797,30 +797,62 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     int tlas_root = -1, tlas_height = 0;
     if (n_meshes > c->tlas_above) {
         std::vector<float> cen(3 * (size_t)n_meshes, 0.f);
-        {
-            std::vector<float> lo(3 * (size_t)n_meshes, INFINITY), hi(3 * (size_t)n_meshes, -INFINITY);
-            for (int i = 0; i < n_tris; i++) {
-                const float* p[3] = {tris[i].posA, tris[i].posB, tris[i].posC};
-                const int j = tris[i].meshIndex;
-                for (int q = 0; q < 3; q++)
-                    for (int a = 0; a < 3; a++) {
-                        lo[3 * j + a] = std::min(lo[3 * j + a], p[q][a]);
-                        hi[3 * j + a] = std::max(hi[3 * j + a], p[q][a]);
-                    }
-            }
-            for (size_t k = 0; k < cen.size(); k++) cen[k] = std::isfinite(lo[k]) && std::isfinite(hi[k]) ? 0.5f * (lo[k] + hi[k]) : 0.f;
+        std::vector<float> box_lo(3 * (size_t)n_meshes, INFINITY), box_hi(3 * (size_t)n_meshes, -INFINITY);
+        for (int i = 0; i < n_tris; i++) {
+            const float* p[3] = {tris[i].posA, tris[i].posB, tris[i].posC};
+            const int j = tris[i].meshIndex;
+            for (int q = 0; q < 3; q++)
+                for (int a = 0; a < 3; a++) {
+                    box_lo[3 * j + a] = std::min(box_lo[3 * j + a], p[q][a]);
+                    box_hi[3 * j + a] = std::max(box_hi[3 * j + a], p[q][a]);
+                }
         }
-        struct Job { std::vector<int> meshes; int depth, parent_rec, which; };
+        for (size_t k = 0; k < cen.size(); k++) cen[k] = std::isfinite(box_lo[k]) && std::isfinite(box_hi[k]) ? 0.5f * (box_lo[k] + box_hi[k]) : 0.f;
+        // topology: a binned-SAH tree over the mesh boxes (rest pose), one mesh per leaf; a leaf the
+        // builder could not split (coinciding centres) is halved by the median rule below
+        std::vector<RtNode48> tn;
+        std::vector<int32_t> tids;
+        int troot;
+        {
+            std::vector<float> fake(9 * (size_t)n_meshes, 0.f);   // "triangle" (lo, hi, lo): same box, same centre
+            std::vector<int32_t> ids(n_meshes);
+            for (int j = 0; j < n_meshes; j++) {
+                ids[j] = j;
+                for (int a = 0; a < 3; a++) {
+                    const bool ok = std::isfinite(box_lo[3 * j + a]) && std::isfinite(box_hi[3 * j + a]);
+                    fake[9 * (size_t)j + a] = fake[9 * (size_t)j + 6 + a] = ok ? box_lo[3 * j + a] : 0.f;
+                    fake[9 * (size_t)j + 3 + a] = ok ? box_hi[3 * j + a] : 0.f;
+                }
+            }
+            troot = rt_sah_build(fake.data(), ids.data(), n_meshes, RT_MAX_STACK - 2, 1, tn, tids);
+        }
+        struct Job { std::vector<int> meshes; int sah_node, depth, parent_rec, which; };
         std::vector<Job> jobs;
-        std::vector<int> all(n_meshes);
-        for (int j = 0; j < n_meshes; j++) all[j] = j;
-        jobs.push_back({all, 0, -1, 0});
+        jobs.push_back({{}, troot, 0, -1, 0});
         const int mesh_depth = max_depth;
         while (!jobs.empty()) {
             Job job = std::move(jobs.back());
             jobs.pop_back();
             int v, ref;
-            if (job.meshes.size() == 1) {                    // a mesh root: nothing new, just link it
+            if (job.sah_node >= 0) {
+                const RtNode48& t = tn[job.sah_node];
+                if (t.c1 < 0 && t.c2 < 0) {                   // a leaf of the SAH tree: its meshes (normally one)
+                    job.meshes.assign(tids.begin() + t.off, tids.begin() + t.off + t.cnt);
+                    job.sah_node = -1;
+                }
+            }
+            if (job.sah_node >= 0) {
+                const RtNode48& t = tn[job.sah_node];
+                v = (int)vnodes.size();
+                vnodes.push_back({-1, -1, 0, 0});
+                vdepth.push_back(job.depth);
+                ref = (int)pack.size();
+                pack.push_back({-1, -1, RT_NONE, RT_NONE});
+                tlas_height = std::max(tlas_height, job.depth + 1);
+                jobs.push_back({{}, t.c1, job.depth + 1, ref, 1});
+                jobs.push_back({{}, t.c2, job.depth + 1, ref, 2});
+                tlas_vnode_of_rec.push_back({ref, v});
+            } else if (job.meshes.size() == 1) {             // a mesh root: nothing new, just link it
                 v = root_v[job.meshes[0]];
                 ref = root_ref[job.meshes[0]];
             } else {
@@ -839,8 +871,8 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
                 ref = (int)pack.size();
                 pack.push_back({-1, -1, RT_NONE, RT_NONE});
                 tlas_height = std::max(tlas_height, job.depth + 1);
-                jobs.push_back({std::vector<int>(job.meshes.begin(), job.meshes.begin() + half), job.depth + 1, ref, 1});
-                jobs.push_back({std::vector<int>(job.meshes.begin() + half, job.meshes.end()), job.depth + 1, ref, 2});
+                jobs.push_back({std::vector<int>(job.meshes.begin(), job.meshes.begin() + half), -1, job.depth + 1, ref, 1});
+                jobs.push_back({std::vector<int>(job.meshes.begin() + half, job.meshes.end()), -1, job.depth + 1, ref, 2});
                 // remember which visit node this record belongs to (for vnode.c1/c2 below)
                 tlas_vnode_of_rec.push_back({ref, v});
             }
