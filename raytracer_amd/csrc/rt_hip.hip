@@ -824,7 +824,9 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
                     fake[9 * (size_t)j + 3 + a] = ok ? box_hi[3 * j + a] : 0.f;
                 }
             }
-            troot = rt_sah_build(fake.data(), ids.data(), n_meshes, RT_MAX_STACK - 2, 1, tn, tids);
+            // depth 12 is ample for the 256 meshes the interface allows; whatever the builder leaves
+            // together at that depth the median rule splits (<= 8 more levels)
+            troot = rt_sah_build(fake.data(), ids.data(), n_meshes, 12, 1, tn, tids);
         }
         struct Job { std::vector<int> meshes; int sah_node, depth, parent_rec, which; };
         std::vector<Job> jobs;
