@@ -266,6 +266,115 @@ struct DevBuf {
 
 }  // namespace
 
+// ---- top-level tree over the mesh roots (scenes with more meshes than the LDS root mask holds) ----
+// Its interior nodes are ordinary 64-byte records whose leaf children ARE the mesh roots (same box,
+// same reference), so the traversal needs nothing new; their boxes are refit with the rest (levels
+// above the mesh levels).  Exactness: a top-level box is the exact union of root boxes, so skipping
+// it is the same conservative shortcut as skipping a missed root box - whatever the topology.
+// Topology: a binned-SAH tree over the mesh boxes handed in (rest-pose boxes at rt_set_scene, posed
+// boxes at every later pose change), one mesh per leaf; a leaf the builder could not split
+// (coinciding centres) is halved by a median rule.  Always n_meshes - 1 interior nodes, so a
+// rebuild overwrites the same device ranges.
+struct TlasHost {
+    std::vector<float> box_lo, box_hi;      // rest-pose box of each mesh
+    std::vector<VNode> vnodes;              // visit nodes: mesh part [0, n_mesh_visits), then the top-level ones
+    std::vector<PackInfo> pack;             // records: mesh part [0, n_mesh_recs), then the top-level ones
+    std::vector<int> vdepth_mesh, root_v, root_ref;
+    size_t n_mesh_visits = 0, n_mesh_recs = 0;
+    int mesh_depth = 0;
+};
+
+void build_tlas(int n_meshes, const float* box_lo, const float* box_hi, const TlasHost& th, std::vector<VNode>& vnodes,
+                std::vector<int>& vdepth, std::vector<PackInfo>& pack, int& tlas_root, int& max_depth) {
+    vnodes.resize(th.n_mesh_visits);
+    pack.resize(th.n_mesh_recs);
+    vdepth = th.vdepth_mesh;
+    std::vector<float> cen(3 * (size_t)n_meshes, 0.f);
+    for (size_t k = 0; k < cen.size(); k++) cen[k] = std::isfinite(box_lo[k]) && std::isfinite(box_hi[k]) ? 0.5f * (box_lo[k] + box_hi[k]) : 0.f;
+    std::vector<RtNode48> tn;
+    std::vector<int32_t> tids;
+    int troot;
+    {
+        std::vector<float> fake(9 * (size_t)n_meshes, 0.f);   // "triangle" (lo, hi, lo): same box, same centre
+        std::vector<int32_t> ids(n_meshes);
+        for (int j = 0; j < n_meshes; j++) {
+            ids[j] = j;
+            for (int a = 0; a < 3; a++) {
+                const bool ok = std::isfinite(box_lo[3 * j + a]) && std::isfinite(box_hi[3 * j + a]);
+                fake[9 * (size_t)j + a] = fake[9 * (size_t)j + 6 + a] = ok ? box_lo[3 * j + a] : 0.f;
+                fake[9 * (size_t)j + 3 + a] = ok ? box_hi[3 * j + a] : 0.f;
+            }
+        }
+        // depth 12 is ample for the 256 meshes the interface allows; whatever the builder leaves
+        // together at that depth the median rule splits (<= 8 more levels)
+        troot = rt_sah_build(fake.data(), ids.data(), n_meshes, 12, 1, tn, tids);
+    }
+    struct Job { std::vector<int> meshes; int sah_node, depth, parent_rec, which; };
+    std::vector<Job> jobs;
+    std::vector<std::pair<int, int>> vnode_of_rec;
+    int tlas_height = 0;
+    tlas_root = -1;
+    jobs.push_back({{}, troot, 0, -1, 0});
+    while (!jobs.empty()) {
+        Job job = std::move(jobs.back());
+        jobs.pop_back();
+        int v, ref;
+        if (job.sah_node >= 0) {
+            const RtNode48& t = tn[job.sah_node];
+            if (t.c1 < 0 && t.c2 < 0) {                   // a leaf of the SAH tree: its meshes (normally one)
+                job.meshes.assign(tids.begin() + t.off, tids.begin() + t.off + t.cnt);
+                job.sah_node = -1;
+            }
+        }
+        if (job.sah_node < 0 && job.meshes.size() == 1) { // a mesh root: nothing new, just link it
+            v = th.root_v[job.meshes[0]];
+            ref = th.root_ref[job.meshes[0]];
+        } else {
+            v = (int)vnodes.size();
+            vnodes.push_back({-1, -1, 0, 0});
+            vdepth.push_back(job.depth);
+            ref = (int)pack.size();
+            pack.push_back({-1, -1, RT_NONE, RT_NONE});
+            tlas_height = std::max(tlas_height, job.depth + 1);
+            vnode_of_rec.push_back({ref, v});
+            if (job.sah_node >= 0) {
+                const RtNode48& t = tn[job.sah_node];
+                jobs.push_back({{}, t.c1, job.depth + 1, ref, 1});
+                jobs.push_back({{}, t.c2, job.depth + 1, ref, 2});
+            } else {
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (int j : job.meshes)
+                    for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], cen[3 * j + a]); hi[a] = std::max(hi[a], cen[3 * j + a]); }
+                int axis = 0;
+                for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+                std::sort(job.meshes.begin(), job.meshes.end(), [&](int x, int y) {
+                    return cen[3 * x + axis] < cen[3 * y + axis] || (cen[3 * x + axis] == cen[3 * y + axis] && x < y);
+                });
+                const size_t half = job.meshes.size() / 2;
+                jobs.push_back({std::vector<int>(job.meshes.begin(), job.meshes.begin() + half), -1, job.depth + 1, ref, 1});
+                jobs.push_back({std::vector<int>(job.meshes.begin() + half, job.meshes.end()), -1, job.depth + 1, ref, 2});
+            }
+        }
+        if (job.parent_rec < 0) tlas_root = ref;
+        else if (job.which == 1) { pack[job.parent_rec].c1 = v; pack[job.parent_rec].ref1 = ref; }
+        else { pack[job.parent_rec].c2 = v; pack[job.parent_rec].ref2 = ref; }
+    }
+    for (auto& rv : vnode_of_rec) { vnodes[rv.second].c1 = pack[rv.first].c1; vnodes[rv.second].c2 = pack[rv.first].c2; }
+    // mesh levels move below the top-level ones: a parent is always refit after its children
+    for (size_t v = 0; v < th.n_mesh_visits; v++) vdepth[v] += tlas_height;
+    max_depth = th.mesh_depth + tlas_height;
+}
+
+// level lists of the refit (level l covers level_nodes[level_off[l] .. level_off[l+1]))
+void level_lists(const std::vector<int>& vdepth, int max_depth, std::vector<int>& level_off, std::vector<int>& level_nodes) {
+    level_off.assign(max_depth + 2, 0);
+    level_nodes.resize(vdepth.size());
+    for (int d : vdepth) level_off[d + 1]++;
+    for (size_t l = 1; l < level_off.size(); l++) level_off[l] += level_off[l - 1];
+    std::vector<int> fill(level_off.begin(), level_off.end() - 1);
+    for (size_t v = 0; v < vdepth.size(); v++) level_nodes[fill[vdepth[v]]++] = (int)v;
+}
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // stream in use
@@ -295,6 +404,11 @@ struct rt_ctx {
     // scene (host mirrors)
     std::vector<float> h_xf;
     std::vector<unsigned char> h_dirty;
+    TlasHost th;                          // host copy of what a rebuild of the top-level tree needs
+    bool tlas_pose_dirty = false;         // a pose changed since the top-level tree was built
+    bool tlas_static = false;             // RT_TLAS_STATIC: keep the rest-pose topology (measurements)
+    std::vector<int> h_level_nodes;       // staging of a rebuild (kept alive for the async copy)
+    std::vector<char> h_has_xf;           // per mesh: a transform has been set (else the mesh is at its rest pose)
     std::vector<int> level_off;           // level l covers level_nodes[level_off[l] .. level_off[l+1])
     std::vector<int> node_first_visit;    // original node id -> visit index (-1 if unreachable)
     std::vector<Std140Node> h_nodes;      // topology as uploaded (for rt_read_nodes48)
@@ -374,8 +488,56 @@ void pose_matrix(const float pos[3], const float q_in[4], float T[16]) {
 }
 
 // pose dirty meshes, refit every level bottom-up, re-pack the traversal records
+// Poses changed in a scene with a top-level tree: its topology is rebuilt from the posed mesh
+// boxes (the 8 corners of each rest-pose box through the mesh's transform: conservative, and only
+// the topology depends on them - the boxes themselves come from the device refit).  ~0.1 ms of
+// host time for 192 meshes; same record and visit-node ranges on the device, new level lists.
+int rebuild_tlas(rt_ctx* c) {
+    TlasHost& th = c->th;
+    const int n = c->n_meshes;
+    std::vector<float> lo(th.box_lo), hi(th.box_hi);
+    for (int j = 0; j < n; j++) {
+        if (!c->h_has_xf[j]) continue;
+        const float* T = &c->h_xf[16 * (size_t)j];
+        const float* rl = &th.box_lo[3 * (size_t)j];
+        const float* rh = &th.box_hi[3 * (size_t)j];
+        if (!(std::isfinite(rl[0]) && std::isfinite(rh[0]))) continue;       // a mesh without triangles
+        float plo[3] = {INFINITY, INFINITY, INFINITY}, phi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < 8; k++) {
+            const float p[3] = {(k & 1) ? rh[0] : rl[0], (k & 2) ? rh[1] : rl[1], (k & 4) ? rh[2] : rl[2]};
+            for (int a = 0; a < 3; a++) {
+                const float q = p[0] * T[0 + a] + p[1] * T[4 + a] + p[2] * T[8 + a] + T[12 + a];
+                plo[a] = std::min(plo[a], q);
+                phi[a] = std::max(phi[a], q);
+            }
+        }
+        for (int a = 0; a < 3; a++) { lo[3 * (size_t)j + a] = plo[a]; hi[3 * (size_t)j + a] = phi[a]; }
+    }
+    std::vector<int> vdepth;
+    int tlas_root = -1, max_depth = 0;
+    build_tlas(n, lo.data(), hi.data(), th, th.vnodes, vdepth, th.pack, tlas_root, max_depth);
+    if (th.vnodes.size() != (size_t)c->n_visit || th.pack.size() != (size_t)c->n_rec)
+        return fail(c, RT_E_STATE, "top-level tree rebuild changed its size");
+    level_lists(vdepth, max_depth, c->level_off, c->h_level_nodes);
+    const size_t nv = th.vnodes.size() - th.n_mesh_visits, nr = th.pack.size() - th.n_mesh_recs;
+    HIPCK(c, hipMemcpyAsync(c->vnodes.p + th.n_mesh_visits, th.vnodes.data() + th.n_mesh_visits, nv * sizeof(VNode), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->pack.p + th.n_mesh_recs, th.pack.data() + th.n_mesh_recs, nr * sizeof(PackInfo), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->level_nodes.p, c->h_level_nodes.data(), c->h_level_nodes.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->tlas_root = tlas_root;
+    if (c->stack_depth != max_depth + 1) {
+        c->stack_depth = max_depth + 1;
+        for (int k = 0; k < 16; k++) c->blocks_per_cu[k] = 0;               // LDS layout and occupancy follow the depth
+    }
+    return RT_OK;
+}
+
 int run_prep(rt_ctx* c) {
     if (!c->prep_pending) return RT_OK;
+    if (c->tlas_root >= 0 && c->tlas_pose_dirty && !c->tlas_static) {
+        int rc = rebuild_tlas(c);                  // its copies complete at the synchronisation below
+        if (rc) return rc;
+    }
+    c->tlas_pose_dirty = false;
     HIPCK(c, hipMemcpyAsync(c->xf.p, c->h_xf.data(), c->h_xf.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(c->dirty.p, c->h_dirty.data(), c->h_dirty.size(), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));   // pageable sources: h_dirty is cleared below
@@ -571,6 +733,7 @@ int rt_create(int device, rt_ctx** out) {
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
     c->stream = c->own_stream;
     if (const char* e = getenv("RT_SAH_LEAF")) c->sah_leaf = std::max(1, std::min(64, atoi(e)));
+    if (const char* e = getenv("RT_TLAS_STATIC")) c->tlas_static = atoi(e) != 0;
     if (const char* e = getenv("RT_TLAS_ABOVE")) c->tlas_above = std::max(1, std::min(32, atoi(e)));
     if (const char* e = getenv("RT_NODE_BIAS")) c->node_bias = atoi(e);
     if (const char* e = getenv("RT_BURST8")) c->burst8 = std::max(0, std::min(64, atoi(e)));
@@ -658,7 +821,6 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     std::vector<float4> rest;
     std::vector<int> slot_mesh, slot_rem, slot_id;
     std::vector<int> first_visit;
-    std::vector<std::pair<int, int>> tlas_vnode_of_rec;
     int max_depth = 0;
     // walks the trees `wn` (roots `wroot[j]`, leaf lists in `wids`) and fills the vectors above
     auto walk = [&](const Std140Node* wn, int wn_count, const int32_t* wids, const std::vector<int>& wroot) -> int {
@@ -790,112 +952,34 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     }
     first_visit = ref_first_visit;          // rt_read_nodes48 maps the REFERENCE's nodes (unavailable with RT_ACCEL_SAH)
     // ---- more than 32 meshes: a top-level tree over the mesh roots replaces the flat mesh loop ----
-    // Its interior nodes are ordinary 64-byte records whose leaf children ARE the mesh roots
-    // (same box, same reference), so the traversal needs nothing new; their boxes are refit with
-    // the rest (levels above the mesh levels).  Exactness: a top-level box is the exact union of
-    // root boxes, so skipping it is the same conservative shortcut as skipping a missed root box.
-    int tlas_root = -1, tlas_height = 0;
+    // (build_tlas; built here from the rest-pose boxes, rebuilt by run_prep whenever poses change)
+    TlasHost th;
+    int tlas_root = -1;
     if (n_meshes > c->tlas_above) {
-        std::vector<float> cen(3 * (size_t)n_meshes, 0.f);
-        std::vector<float> box_lo(3 * (size_t)n_meshes, INFINITY), box_hi(3 * (size_t)n_meshes, -INFINITY);
+        th.box_lo.assign(3 * (size_t)n_meshes, INFINITY);
+        th.box_hi.assign(3 * (size_t)n_meshes, -INFINITY);
         for (int i = 0; i < n_tris; i++) {
             const float* p[3] = {tris[i].posA, tris[i].posB, tris[i].posC};
             const int j = tris[i].meshIndex;
             for (int q = 0; q < 3; q++)
                 for (int a = 0; a < 3; a++) {
-                    box_lo[3 * j + a] = std::min(box_lo[3 * j + a], p[q][a]);
-                    box_hi[3 * j + a] = std::max(box_hi[3 * j + a], p[q][a]);
+                    th.box_lo[3 * j + a] = std::min(th.box_lo[3 * j + a], p[q][a]);
+                    th.box_hi[3 * j + a] = std::max(th.box_hi[3 * j + a], p[q][a]);
                 }
         }
-        for (size_t k = 0; k < cen.size(); k++) cen[k] = std::isfinite(box_lo[k]) && std::isfinite(box_hi[k]) ? 0.5f * (box_lo[k] + box_hi[k]) : 0.f;
-        // topology: a binned-SAH tree over the mesh boxes (rest pose), one mesh per leaf; a leaf the
-        // builder could not split (coinciding centres) is halved by the median rule below
-        std::vector<RtNode48> tn;
-        std::vector<int32_t> tids;
-        int troot;
-        {
-            std::vector<float> fake(9 * (size_t)n_meshes, 0.f);   // "triangle" (lo, hi, lo): same box, same centre
-            std::vector<int32_t> ids(n_meshes);
-            for (int j = 0; j < n_meshes; j++) {
-                ids[j] = j;
-                for (int a = 0; a < 3; a++) {
-                    const bool ok = std::isfinite(box_lo[3 * j + a]) && std::isfinite(box_hi[3 * j + a]);
-                    fake[9 * (size_t)j + a] = fake[9 * (size_t)j + 6 + a] = ok ? box_lo[3 * j + a] : 0.f;
-                    fake[9 * (size_t)j + 3 + a] = ok ? box_hi[3 * j + a] : 0.f;
-                }
-            }
-            // depth 12 is ample for the 256 meshes the interface allows; whatever the builder leaves
-            // together at that depth the median rule splits (<= 8 more levels)
-            troot = rt_sah_build(fake.data(), ids.data(), n_meshes, 12, 1, tn, tids);
-        }
-        struct Job { std::vector<int> meshes; int sah_node, depth, parent_rec, which; };
-        std::vector<Job> jobs;
-        jobs.push_back({{}, troot, 0, -1, 0});
-        const int mesh_depth = max_depth;
-        while (!jobs.empty()) {
-            Job job = std::move(jobs.back());
-            jobs.pop_back();
-            int v, ref;
-            if (job.sah_node >= 0) {
-                const RtNode48& t = tn[job.sah_node];
-                if (t.c1 < 0 && t.c2 < 0) {                   // a leaf of the SAH tree: its meshes (normally one)
-                    job.meshes.assign(tids.begin() + t.off, tids.begin() + t.off + t.cnt);
-                    job.sah_node = -1;
-                }
-            }
-            if (job.sah_node >= 0) {
-                const RtNode48& t = tn[job.sah_node];
-                v = (int)vnodes.size();
-                vnodes.push_back({-1, -1, 0, 0});
-                vdepth.push_back(job.depth);
-                ref = (int)pack.size();
-                pack.push_back({-1, -1, RT_NONE, RT_NONE});
-                tlas_height = std::max(tlas_height, job.depth + 1);
-                jobs.push_back({{}, t.c1, job.depth + 1, ref, 1});
-                jobs.push_back({{}, t.c2, job.depth + 1, ref, 2});
-                tlas_vnode_of_rec.push_back({ref, v});
-            } else if (job.meshes.size() == 1) {             // a mesh root: nothing new, just link it
-                v = root_v[job.meshes[0]];
-                ref = root_ref[job.meshes[0]];
-            } else {
-                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-                for (int j : job.meshes)
-                    for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], cen[3 * j + a]); hi[a] = std::max(hi[a], cen[3 * j + a]); }
-                int axis = 0;
-                for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
-                std::sort(job.meshes.begin(), job.meshes.end(), [&](int x, int y) {
-                    return cen[3 * x + axis] < cen[3 * y + axis] || (cen[3 * x + axis] == cen[3 * y + axis] && x < y);
-                });
-                const size_t half = job.meshes.size() / 2;
-                v = (int)vnodes.size();
-                vnodes.push_back({-1, -1, 0, 0});
-                vdepth.push_back(job.depth);
-                ref = (int)pack.size();
-                pack.push_back({-1, -1, RT_NONE, RT_NONE});
-                tlas_height = std::max(tlas_height, job.depth + 1);
-                jobs.push_back({std::vector<int>(job.meshes.begin(), job.meshes.begin() + half), -1, job.depth + 1, ref, 1});
-                jobs.push_back({std::vector<int>(job.meshes.begin() + half, job.meshes.end()), -1, job.depth + 1, ref, 2});
-                // remember which visit node this record belongs to (for vnode.c1/c2 below)
-                tlas_vnode_of_rec.push_back({ref, v});
-            }
-            if (job.parent_rec < 0) tlas_root = ref;
-            else if (job.which == 1) { pack[job.parent_rec].c1 = v; pack[job.parent_rec].ref1 = ref; }
-            else { pack[job.parent_rec].c2 = v; pack[job.parent_rec].ref2 = ref; }
-        }
-        for (auto& rv : tlas_vnode_of_rec) { vnodes[rv.second].c1 = pack[rv.first].c1; vnodes[rv.second].c2 = pack[rv.first].c2; }
-        // mesh levels move below the top-level ones: a parent is always refit after its children
-        const size_t n_mesh_visits = vnodes.size() - tlas_vnode_of_rec.size();
-        for (size_t v = 0; v < n_mesh_visits; v++) vdepth[v] += tlas_height;
-        max_depth = mesh_depth + tlas_height;
+        th.n_mesh_visits = vnodes.size();
+        th.n_mesh_recs = pack.size();
+        th.mesh_depth = max_depth;
+        th.vdepth_mesh = vdepth;
+        th.root_v = root_v;
+        th.root_ref = root_ref;
+        build_tlas(n_meshes, th.box_lo.data(), th.box_hi.data(), th, vnodes, vdepth, pack, tlas_root, max_depth);
+        th.vnodes = vnodes;
+        th.pack = pack;
     }
     // level lists (deepest first at refit time)
-    std::vector<int> level_off(max_depth + 2, 0), level_nodes(vnodes.size());
-    for (int d : vdepth) level_off[d + 1]++;
-    for (size_t l = 1; l < level_off.size(); l++) level_off[l] += level_off[l - 1];
-    {
-        std::vector<int> fill(level_off.begin(), level_off.end() - 1);
-        for (size_t v = 0; v < vnodes.size(); v++) level_nodes[fill[vdepth[v]]++] = (int)v;
-    }
+    std::vector<int> level_off, level_nodes;
+    level_lists(vdepth, max_depth, level_off, level_nodes);
 
     // ---- upload ----
     free_scene(c);
@@ -933,11 +1017,14 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     HIPCK(c, c->dirty.alloc((size_t)std::max(n_meshes, 1)));
     c->h_xf.assign(16 * (size_t)std::max(n_meshes, 1), 0.f);
     c->h_dirty.assign((size_t)std::max(n_meshes, 1), 2);        // 2 = copy rest pose as given
+    c->h_has_xf.assign((size_t)std::max(n_meshes, 1), 0);
     c->level_off = level_off;
     c->stack_depth = max_depth + 1;
     for (int k = 0; k < 16; k++) c->blocks_per_cu[k] = 0;   // LDS layout and occupancy are per scene
     if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] scene: %d slots, %d records, max depth %d, %s\n", c->n_slots, c->n_rec, max_depth, sah ? "SAH" : "reference structure");
     c->tlas_root = tlas_root;
+    c->th = std::move(th);
+    c->tlas_pose_dirty = false;
     c->scene_is_sah = sah;
     c->node_first_visit = first_visit;
     c->h_nodes.assign(nodes, nodes + n_nodes);
@@ -970,6 +1057,8 @@ int rt_update_mesh_transform(rt_ctx* c, int mesh, const float T16[16]) {
     if (mesh < 0 || mesh >= c->n_meshes) return fail(c, RT_E_ARG, "mesh index out of range");
     std::memcpy(&c->h_xf[16 * (size_t)mesh], T16, 64);
     c->h_dirty[mesh] = 1;
+    c->h_has_xf[mesh] = 1;
+    c->tlas_pose_dirty = true;
     c->prep_pending = true;      // batched: all dirty meshes are posed by one launch before the next use
     return RT_OK;
 }
