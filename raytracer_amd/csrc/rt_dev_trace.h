@@ -23,9 +23,12 @@
 //            flags = mesh index | RT_TFB_BIT (the mesh's transparentFromBehind).
 //   tri_nrm  3 x float4 per slot (corner normals; .w of the first = mesh index).
 //   nodes    4 x float4 per INTERIOR node: both children's boxes and references
-//              {lo1.xyz, bits(ref1)} {hi1.xyz, bits(ref2)} {lo2.xyz, 0} {hi2.xyz, 0}
-//            ref >= 0: interior record index; ref < 0 and != RT_NONE: leaf, first slot = ~ref.
-//   roots    2 x float4 per mesh: {lo.xyz, bits(ref)} {hi.xyz, 0} of the mesh's root node.
+//              {lo1.xyz, bits(ref1)} {hi1.xyz, bits(ref2)} {lo2.xyz, e1} {hi2.xyz, e2}
+//            ref >= 0: interior record index; ref < 0 and != RT_NONE: leaf, first slot = ~ref;
+//            e = slack of the child's widened slab test (RT_ACCEL_SAH scenes; 0 otherwise).
+//   roots    2 x float4 per mesh: {lo.xyz, bits(ref)} {hi.xyz, e} of the mesh's root node.
+//   tri_box  RT_ACCEL_SAH scenes: 2 x float4 per slot, the box of the triangle's leaf in the
+//            REFERENCE's tree (what decides whether a hit found through the SAH tree counts).
 //   mats     the 80-byte std140 Material of every mesh, as uploaded.
 //   totals   one float3 per (pass, pixel) of the launch: k_trace writes, k_accumulate folds.
 //
@@ -37,7 +40,8 @@
 // triangle steps in bursts, and when fewer than `refill_below` lanes still traverse, the lanes
 // that wait shade their hit and start their next ray in one path block.  The order in which a
 // lane meets its boxes and triangles changes with the votes; the result does not: it is the
-// minimum of (t, slot rank) over the same set of tests.
+// minimum of (t, slot rank) over the same set of tests.  Node stack entries beyond the ones that
+// fit in LDS at full occupancy live in global memory (DEEP instantiations).
 #pragma once
 #include "rt_dev_math.h"
 
