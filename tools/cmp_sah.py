@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The opt-in SAH structure against the reference structure on the bench frame: differing first
 hits / pixels, tests per ray, kernel time.
-usage: python tools/cmp_sah.py [passes] [width height] [bounces]   (RT_FRAMES=0,40,... optional)"""
+usage: python tools/cmp_sah.py [passes] [width height] [bounces]
+       RT_FRAMES=0,40,...  animation frames; RT_SCENE=suzanne (default) | suzanneN (N x subdivided) | dragon | dragon_animated"""
 import os
 import sys
 from pathlib import Path
@@ -17,15 +18,31 @@ w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 108
 bounces = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 frames = [int(x) for x in os.environ.get("RT_FRAMES", "0").split(",")]
 lib = ffi.RtLib(os.environ.get("RT_LIB") or None)
+which = os.environ.get("RT_SCENE", "suzanne")
+
+
+def build_scene():
+    if which == "dragon":
+        from raytracer_amd.scripts.scenes import dragon_scene as D
+        return D.build()
+    if which == "dragon_animated":
+        from raytracer_amd.scripts.scenes import dragon_scene_animated as D
+        return D.build()
+    if which != "suzanne":
+        return S.build(subdivide=int(which[7:]), lib=lib)
+    return S.build()
+
+
 tot_px = tot_ids = 0
 for frame in frames:
     res = {}
     for name, sah, cull in (("reference strict", False, False), ("reference cull", False, True), ("SAH cull", True, True)):
-        sc = S.build()
-        sc.animate_frame(frame)
+        sc = build_scene()
         ctx = lib.create(0)
         ctx.set_accel(sah)
-        ctx.load_scene(sc)
+        ctx.load_scene(sc)                  # uploaded as built, then the frame's poses (the reference's order)
+        sc.animate_frame(frame)
+        ctx.update_scene(sc)
         ctx.load_camera(sc.cam)
         ctx.resize(w, h)
         ctx.set_cull(cull)
@@ -51,4 +68,4 @@ for frame in frames:
     print(f"frame {frame}: SAH vs reference: {d_ids} first-hit ids differ, {d_px} of {w*h} pixels differ (max abs {err:.3g})")
     tot_px += d_px
     tot_ids += d_ids
-print(f"TOTAL over {len(frames)} frames: {tot_ids} first-hit ids, {tot_px} pixels differ")
+print(f"scene {which}, {w}x{h}, {passes} passes, {bounces} bounces.  TOTAL over {len(frames)} frames: {tot_ids} first-hit ids, {tot_px} pixels differ")
