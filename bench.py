@@ -223,7 +223,7 @@ def main() -> None:
             "roofline": {
                 "bound": "mfma",
                 "engine": "f32 VALU (no GEMM shape on this path; the f32 vector-FMA peak equals the dense f32 MFMA peak)",
-                "kernel": "k_trace<STATS=false,CULL=%s,FIRST_HIT=false,SAH=%s>" % ("false" if args.strict else "true", "false" if args.reference_structure else "true"),
+                "kernel": "k_trace<STATS=false,CULL=%s,FIRST_HIT=false,SAH=%s,DEEP=false>" % ("false" if args.strict else "true", "false" if args.reference_structure else "true"),
                 "achieved": round(achieved_tflops, 3),
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
