@@ -27,6 +27,12 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 WIDTH, HEIGHT, PASSES, RPP, BOUNCES = 1920, 1080, 64, 1, 4
+# RT_BENCH_REHEARSAL=1: a tiny frame, ONLY to walk the N > 1 code path with several ranks sharing one
+# GPU (two full-size persistent kernels time-slice pathologically there); its line says so and is
+# not a measurement
+REHEARSAL = os.environ.get("RT_BENCH_REHEARSAL", "0") == "1"
+if REHEARSAL:
+    WIDTH, HEIGHT, PASSES = 320, 180, 4
 # algorithmic work per unit (DESIGN.md "roofline accounting")
 FLOP_BOX, FLOP_TRI, FLOP_HIT = 27, 47, 160
 BYTE_BOX, BYTE_TRI, BYTE_HIT = 32, 36, 48
@@ -40,7 +46,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-passes", type=int, default=3)
+    ap.add_argument("--cpu-passes", type=int, default=20, help="passes of the CPU baseline sample (20 = about 15 s on 16 threads)")
     ap.add_argument("--strict", action="store_true", help="visit exactly the reference's box set (no distance culling)")
     ap.add_argument("--reference-structure", action="store_true", help="traverse the reference's own BVH instead of the SAH one")
     args = ap.parse_args()
@@ -243,6 +249,8 @@ def main() -> None:
             "cpu_baseline": cpu,
             "reference_structure": other,
         }
+        if REHEARSAL:
+            out["rehearsal"] = "RT_BENCH_REHEARSAL=1: 320x180, 4 passes - not a measurement"
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
