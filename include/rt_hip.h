@@ -65,6 +65,21 @@ typedef struct rt_stats_t {
     uint64_t sched[6];
 } rt_stats_t;
 
+/* What rt_set_scene built and how the most recent k_trace launch was laid out (for tests and
+ * tuning; NO counterpart in the reference).  Oracle: the scene counts, everything else 0. */
+typedef struct rt_info_t {
+    int32_t accel;              /* RT_ACCEL_* of the scene in place                                        */
+    int32_t n_slots;            /* triangle slots (triangles reachable through the BVHs)                   */
+    int32_t n_records;          /* interior traversal records (64 B each), top-level tree included         */
+    int32_t top_level_tree;     /* 1: more meshes than the LDS root mask holds, traversal starts at a tree */
+    int32_t stack_entries;      /* node stack entries a lane can need (tree depth + 1)                     */
+    int32_t stack_entries_lds;  /* of these, kept in LDS by the most recent launch (rest: global memory)   */
+    int32_t lds_bytes;          /* dynamic LDS per workgroup of that launch                                */
+    int32_t workgroups_per_cu;  /* resident workgroups per CU of that launch                               */
+    int32_t top_level_rebuilds; /* times the top-level tree was rebuilt from posed boxes                   */
+    int32_t reserved[7];
+} rt_info_t;
+
 /* replaces: ProgramABC.__init__/initialise creating the GL context (application.py:499-575) */
 int rt_create(int device, rt_ctx** out);
 int rt_destroy(rt_ctx* ctx);
@@ -176,6 +191,7 @@ int rt_set_cull(rt_ctx* ctx, int enable);
 int rt_enable_stats(rt_ctx* ctx, int enable);
 int rt_reset_stats(rt_ctx* ctx);
 int rt_get_stats(rt_ctx* ctx, rt_stats_t* out);
+int rt_get_info(rt_ctx* ctx, rt_info_t* out);
 
 /* launch on a caller-provided hipStream_t (e.g. torch's current stream, so that a
  * torch.distributed all-reduce of the bound accumulator is ordered after the render

@@ -828,6 +828,15 @@ int rt_read_mean(rt_ctx* c, float* out) {
 int rt_enable_stats(rt_ctx* c, int e) { (void)e; return c ? RT_OK : RT_E_ARG; }
 int rt_reset_stats(rt_ctx* c) { if (!c) return RT_E_ARG; memset(&c->st, 0, sizeof c->st); return RT_OK; }
 int rt_get_stats(rt_ctx* c, rt_stats_t* o) { if (!c || !o) return RT_E_ARG; *o = c->st; return RT_OK; }
+/* the oracle walks the uploaded trees with a plain stack: only the scene counts mean anything here */
+int rt_get_info(rt_ctx* c, rt_info_t* o) {
+    if (!c || !o) return RT_E_ARG;
+    memset(o, 0, sizeof(*o));
+    if (!c->have_scene) FAIL(c, RT_E_STATE, "no scene");
+    o->n_slots = c->n_tris;
+    o->n_records = c->n_nodes;
+    return RT_OK;
+}
 int rt_sync(rt_ctx* c) { return c ? RT_OK : RT_E_ARG; }
 int rt_set_cull(rt_ctx* c, int e) { (void)e; return c ? RT_OK : RT_E_ARG; } /* the oracle never culls */
 int rt_set_accel(rt_ctx* c, int accel) { (void)accel; return c ? RT_OK : RT_E_ARG; }   /* one structure only: the reference's */

@@ -399,6 +399,8 @@ struct rt_ctx {
     int stack_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // per k_trace variant: node stack entries in LDS for the scene in place
     DevBuf<int2> stack_ovf;               // deeper entries (rare): (stack_depth - cap) x launch lanes
     size_t stack_ovf_n = 0;
+    int last_stack_lds = 0, last_lds_bytes = 0, last_blocks_per_cu = 0;   // layout of the most recent k_trace launch (rt_get_info)
+    int tlas_rebuilds = 0;
     int stack_lds_force = 0;              // RT_STACK_LDS: LDS node stack entries, whatever the occupancy (tests of the deep-entry path)
     int blocks_per_cu[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // per k_trace variant, for the scene in place (0 = not yet asked)
     // scene (host mirrors)
@@ -524,6 +526,7 @@ int rebuild_tlas(rt_ctx* c) {
     HIPCK(c, hipMemcpyAsync(c->pack.p + th.n_mesh_recs, th.pack.data() + th.n_mesh_recs, nr * sizeof(PackInfo), hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(c->level_nodes.p, c->h_level_nodes.data(), c->h_level_nodes.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     c->tlas_root = tlas_root;
+    c->tlas_rebuilds++;
     if (c->stack_depth != max_depth + 1) {
         c->stack_depth = max_depth + 1;
         for (int k = 0; k < 16; k++) c->blocks_per_cu[k] = 0;               // LDS layout and occupancy follow the depth
@@ -637,6 +640,9 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
         c->stack_ovf_n = need_ovf;
     }
     b.stack_ovf = c->stack_ovf.p;
+    c->last_stack_lds = cap;
+    c->last_lds_bytes = (int)lds;
+    c->last_blocks_per_cu = c->blocks_per_cu[key];
     HIPCK(c, hipMemsetAsync(c->work_counter.p, 0, sizeof(unsigned int), c->stream));
     hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST, SAH, DEEP>), dim3(grid), dim3(RT_BLOCK), lds, c->stream, b);
     return RT_OK;
@@ -1308,6 +1314,22 @@ int rt_reset_stats(rt_ctx* c) {
     if (rc) return rc;
     HIPCK(c, hipMemsetAsync(c->counters.p, 0, 128, c->stream));
     c->st = rt_stats_t{};
+    return RT_OK;
+}
+
+int rt_get_info(rt_ctx* c, rt_info_t* o) {
+    if (!c || !o) return RT_E_ARG;
+    std::memset(o, 0, sizeof(*o));
+    if (!c->have_scene) return fail(c, RT_E_STATE, "no scene");
+    o->accel = c->scene_is_sah ? RT_ACCEL_SAH : RT_ACCEL_REFERENCE;
+    o->n_slots = c->n_slots;
+    o->n_records = c->n_rec;
+    o->top_level_tree = c->tlas_root >= 0;
+    o->stack_entries = c->stack_depth;
+    o->stack_entries_lds = c->last_stack_lds;
+    o->lds_bytes = c->last_lds_bytes;
+    o->workgroups_per_cu = c->last_blocks_per_cu;
+    o->top_level_rebuilds = c->tlas_rebuilds;
     return RT_OK;
 }
 

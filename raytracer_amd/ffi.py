@@ -35,6 +35,14 @@ class RtStats(C.Structure):
         return d
 
 
+class RtInfo(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("accel", "n_slots", "n_records", "top_level_tree", "stack_entries", "stack_entries_lds",
+                                         "lds_bytes", "workgroups_per_cu", "top_level_rebuilds")] + [("reserved", C.c_int32 * 7)]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
 class RtError(RuntimeError):
     def __init__(self, code: int, where: str, text: str):
         super().__init__(f"{where} failed with code {code}: {text}")
@@ -69,6 +77,7 @@ _SIGNATURES = {
     "rt_enable_stats": (C.c_int, [_vp, C.c_int]),
     "rt_reset_stats": (C.c_int, [_vp]),
     "rt_get_stats": (C.c_int, [_vp, C.POINTER(RtStats)]),
+    "rt_get_info": (C.c_int, [_vp, C.POINTER(RtInfo)]),
     "rt_sync": (C.c_int, [_vp]),
     "rt_set_stream": (C.c_int, [_vp, _vp]),
     "rt_stream": (_vp, [_vp]),
@@ -268,6 +277,12 @@ class RtContext:
         s = RtStats()
         self._ck(self.lib.dll.rt_get_stats(self._h, C.byref(s)), "rt_get_stats")
         return s.as_dict()
+
+    def info(self) -> dict:
+        """What rt_set_scene built and how the most recent trace launch was laid out (rt_info_t)."""
+        i = RtInfo()
+        self._ck(self.lib.dll.rt_get_info(self._h, C.byref(i)), "rt_get_info")
+        return i.as_dict()
 
     def sync(self) -> None:
         self._ck(self.lib.dll.rt_sync(self._h), "rt_sync")

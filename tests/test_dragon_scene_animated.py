@@ -91,4 +91,9 @@ def test_animated_dragon_bit_exact(oracle_lib, hip_lib, scene):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"frame {f} {name}: {(a != b).any(axis=2).sum()} pixels differ"
         moved += int((io != res[-1][0][0]).sum())
     assert moved > 100                                               # the cubes did move through the view
+    for ctx in (strict, cull, sah):
+        i = ctx.info()
+        # the top-level tree follows the poses; a 29-level stack keeps 6 workgroups per CU by capping its LDS part
+        assert i["top_level_tree"] == 1 and i["top_level_rebuilds"] >= len(frames)
+        assert i["stack_entries_lds"] < i["stack_entries"] and i["workgroups_per_cu"] >= 6
     assert len(np.unique(res[-1][0][0])) > 300

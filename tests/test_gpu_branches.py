@@ -68,14 +68,17 @@ def test_deep_stack_entries_in_global_memory(hip_lib, monkeypatch):
         c.enable_stats(True)
         ids, ts = c.first_hit(1)
         c.render(1, 2, 1, 2, 4, 0)
-        return ids, ts, c.read_mean(), c.stats()
+        return ids, ts, c.read_mean(), c.stats(), c.info()
 
     for sah, cull in ((False, False), (False, True), (True, True)):
         a = run(sah, cull)
+        assert a[4]["stack_entries_lds"] == a[4]["stack_entries"] > 8 and a[4]["workgroups_per_cu"] >= 6   # Suzanne fits
+        assert a[4]["accel"] == int(sah) and a[4]["top_level_tree"] == 0
         for n in (1, 2):
             monkeypatch.setenv("RT_STACK_LDS", str(n))
             b = run(sah, cull)
             monkeypatch.delenv("RT_STACK_LDS")
+            assert b[4]["stack_entries_lds"] == n < b[4]["stack_entries"]                                     # the switch did switch
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
             assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
             for k in ("rays", "box_tests", "tri_tests", "shaded_hits"):
