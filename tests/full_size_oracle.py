@@ -3,7 +3,11 @@
 configs[1] at its FULL size - Suzanne room, 1920x1080, 64 passes x 1 ray per pixel, 4 bounces - rendered by the
 CPU oracle and by the HIP library in every mode; first-hit ids, distances and the float bit patterns of the
 mean image must be identical, and so must the ray / triangle-test / hit counters of the exact mode.
-usage: python tests/full_size_oracle.py [passes]"""
+usage: python tests/full_size_oracle.py [passes]
+       RT_SCENE=dragon    : configs[4], the 192-mesh dragon scene, 1920x1080, 8 bounces
+       RT_SCENE=suzanne5  : configs[3], 991 316 triangles, 3840x2160, 4 bounces (give a small pass count: the
+                            oracle does ~20 Mrays/s)"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -16,12 +20,24 @@ from raytracer_amd import ffi
 from raytracer_amd.scripts.scenes import final_scene_numba as S
 
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-W, H, BOUNCES = 1920, 1080, 4
+which = os.environ.get("RT_SCENE", "suzanne")
+W, H, BOUNCES = {"suzanne": (1920, 1080, 4), "dragon": (1920, 1080, 8), "suzanne5": (3840, 2160, 4)}[which]
+_hip_for_build = ffi.RtLib()
+
+
+def build_scene():
+    if which == "dragon":
+        from raytracer_amd.scripts.scenes import dragon_scene as D
+        return D.build()
+    if which == "suzanne5":
+        return S.build(subdivide=5, lib=_hip_for_build)      # the native builder (rt_bvh_build): host code of the library
+    sc = S.build()
+    sc.animate_frame(0)
+    return sc
 
 
 def render(lib, sah, cull):
-    sc = S.build()
-    sc.animate_frame(0)
+    sc = build_scene()
     c = lib.create(0)
     c.set_accel(sah)
     c.load_scene(sc)
@@ -51,5 +67,5 @@ for name, sah, cull in (("exact", False, False), ("culled", False, True), ("SAH 
     ok = ok and d_ids == 0 and d_px == 0 and same_counts
     print(f"HIP {name:10s}: {d_ids} first hits differ, {d_px} of {W*H} pixels differ, counters {'equal' if same_counts else 'DIFFER'} "
           f"(rays {r[3]['rays']}, triangle tests {r[3]['tri_tests']})", flush=True)
-print(f"configs[1] full size, {passes} passes: " + ("HIP == oracle bit for bit in every mode" if ok else "MISMATCH"))
+print(f"scene {which}, {W}x{H}, {passes} passes, {BOUNCES} bounces: " + ("HIP == oracle bit for bit in every mode" if ok else "MISMATCH"))
 sys.exit(0 if ok else 1)
