@@ -32,7 +32,7 @@ def build_scene():
     if which == "suzanne5":
         return S.build(subdivide=5, lib=_hip_for_build)      # the native builder (rt_bvh_build): host code of the library
     sc = S.build()
-    sc.animate_frame(0)
+    sc.animate_frame(int(os.environ.get("RT_FRAME", "0")))      # configs[2]: any frame of the keyframe animation
     return sc
 
 
@@ -67,5 +67,5 @@ for name, sah, cull in (("exact", False, False), ("culled", False, True), ("SAH 
     ok = ok and d_ids == 0 and d_px == 0 and same_counts
     print(f"HIP {name:10s}: {d_ids} first hits differ, {d_px} of {W*H} pixels differ, counters {'equal' if same_counts else 'DIFFER'} "
           f"(rays {r[3]['rays']}, triangle tests {r[3]['tri_tests']})", flush=True)
-print(f"scene {which}, {W}x{H}, {passes} passes, {BOUNCES} bounces: " + ("HIP == oracle bit for bit in every mode" if ok else "MISMATCH"))
+print(f"scene {which} frame {os.environ.get('RT_FRAME', '0')}, {W}x{H}, {passes} passes, {BOUNCES} bounces: " + ("HIP == oracle bit for bit in every mode" if ok else "MISMATCH"))
 sys.exit(0 if ok else 1)
