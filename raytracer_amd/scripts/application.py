@@ -157,6 +157,73 @@ def read_pfm(path) -> np.ndarray:
     return data.reshape(h, w, 3)
 
 
+def write_exr(path, img_top_down: np.ndarray) -> None:
+    """OpenEXR 2 scanline file, uncompressed, three FLOAT channels (stored B, G, R: the format wants
+    them alphabetical), rows top-to-bottom - what the reference's ``imageio.imwrite(..., format="exr")`` of
+    the flipped float32 frame holds (application.py:1117), written without imageio."""
+    import struct
+
+    img = np.ascontiguousarray(img_top_down, dtype="<f4")
+    h, w, c = img.shape
+    assert c == 3
+
+    def attr(name: str, typ: str, value: bytes) -> bytes:
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(value)) + value
+
+    chlist = b"".join(n + b"\0" + struct.pack("<iB3xii", 2, 0, 1, 1) for n in (b"B", b"G", b"R")) + b"\0"
+    window = struct.pack("<4i", 0, 0, w - 1, h - 1)
+    header = (struct.pack("<ii", 20000630, 2)
+              + attr("channels", "chlist", chlist)
+              + attr("compression", "compression", b"\0")
+              + attr("dataWindow", "box2i", window)
+              + attr("displayWindow", "box2i", window)
+              + attr("lineOrder", "lineOrder", b"\0")
+              + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+              + attr("screenWindowCenter", "v2f", struct.pack("<2f", 0.0, 0.0))
+              + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+              + b"\0")
+    row_bytes = 3 * w * 4
+    first = len(header) + 8 * h
+    offsets = np.arange(h, dtype="<u8") * (8 + row_bytes) + first
+    rows = np.empty((h, 8 + row_bytes), dtype=np.uint8)
+    rows[:, 0:4] = np.arange(h, dtype="<i4").view(np.uint8).reshape(h, 4)
+    rows[:, 4:8] = np.frombuffer(struct.pack("<i", row_bytes), dtype=np.uint8)
+    # per scanline: all B, then all G, then all R
+    rows[:, 8:] = np.ascontiguousarray(img[:, :, ::-1].transpose(0, 2, 1)).view(np.uint8).reshape(h, row_bytes)
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(offsets.tobytes())
+        f.write(rows.tobytes())
+
+
+def read_exr(path) -> np.ndarray:
+    """Reader for the files ``write_exr`` makes (uncompressed scanline FLOAT B/G/R) -> (h, w, 3) RGB, top-down."""
+    import struct
+
+    data = open(path, "rb").read()
+    assert struct.unpack_from("<ii", data, 0) == (20000630, 2)
+    pos, attrs = 8, {}
+    while data[pos] != 0:
+        end = data.index(b"\0", pos)
+        name = data[pos:end].decode()
+        tend = data.index(b"\0", end + 1)
+        size = struct.unpack_from("<i", data, tend + 1)[0]
+        attrs[name] = data[tend + 5:tend + 5 + size]
+        pos = tend + 5 + size
+    pos += 1
+    assert attrs["compression"] == b"\0" and attrs["lineOrder"] == b"\0"
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    offsets = np.frombuffer(data, dtype="<u8", count=h, offset=pos)
+    out = np.empty((h, w, 3), dtype=np.float32)
+    for off in offsets:
+        y, size = struct.unpack_from("<ii", data, int(off))
+        assert size == 3 * w * 4
+        bgr = np.frombuffer(data, dtype="<f4", count=3 * w, offset=int(off) + 8).reshape(3, w)
+        out[y - y0] = bgr[::-1].T
+    return out
+
+
 class ProgramABC(ABC):
     """Plugin interface of a render program (application.py:475-611)."""
 
@@ -290,8 +357,8 @@ class RayTracerDynamic(ProgramABC):
     # -- application.py:1094-1126 -------------------------------------------------------------
     def save_frame(self, fbo, frame, cycle) -> None:
         """PNG (clip -> *255 -> uint8, row 0 = top, application.py:1104-1117) + the float32 image as
-        .npy and as PFM (the reference writes EXR via imageio, :1118-1126, which is absent here;
-        PFM is the HDR format that needs no library: bottom-up scanlines, like fbo.read)."""
+        OpenEXR with the reference's file name (``_f4.exr``, :1117; written by ``write_exr``, imageio is
+        absent here), and additionally as .npy and PFM (bottom-up scanlines, like fbo.read)."""
         from PIL import Image
 
         if not hasattr(self, "target_dir"):
@@ -304,6 +371,7 @@ class RayTracerDynamic(ProgramABC):
         Image.fromarray(rgb8, "RGB").save(self.target_dir / f"{stem}_f1.png")
         np.save(self.target_dir / f"{stem}_f4.npy", flipped)
         write_pfm(self.target_dir / f"{stem}_f4.pfm", hdr)
+        write_exr(self.target_dir / f"{stem}_f4.exr", flipped)
 
     def handle_event(self, event, app, cam, scene, keyboard_enabled, mouse_enabled):
         return
