@@ -136,7 +136,7 @@ int rt_bvh_refit(const float* pos9, int n_tris, int32_t first_tri_id, int32_t fi
 /* NO counterpart in the reference: which per-mesh tree the NEXT rt_set_scene builds on the device.
  * RT_ACCEL_REFERENCE (default): the uploaded nodes, i.e. the reference's own BVH - the parity
  * structure, results identical to the reference's traversal.  RT_ACCEL_SAH: a binned-SAH tree with
- * leaves of <= 4 triangles over the same triangles ("performance
+ * leaves of <= 3 triangles over the same triangles ("performance
  * structure").  Same results: equal-distance hits resolve in the reference's order, the slab tests
  * are widened so that no triangle the reference could hit is missed, and a hit counts only if the
  * ray passes the box of the triangle's leaf in the REFERENCE's tree, so the candidate set is the

@@ -209,6 +209,14 @@ enum { M_TRAV = 0, M_PATH = 2, M_DONE = 3 };
 #ifndef RT_LQ
 #define RT_LQ 2
 #endif
+// RT_ACCEL_SAH scenes: a third slot lets a lane with one leaf waiting still join node steps (leaves
+// of <= 4 triangles are soon done, so the later culling costs little): lanes per node step
+// 38.7 -> 41.7, per triangle step 34.1 -> 38.7, 2-3 % on every scene.  With the reference's
+// larger leaves the same slot costs 8 % (triangle tests start later and cull less).
+#ifndef RT_LQ_SAH
+#define RT_LQ_SAH 3
+#endif
+#define RT_LQ_OF(sah) ((sah) ? RT_LQ_SAH : RT_LQ)
 #define RT_MIN_STACK_LDS 4         // node stack entries a lane always has in LDS
 #define RT_TFB_BIT 0x40000000      // tri_geo[3].w = mesh index | RT_TFB_BIT if the mesh is transparentFromBehind
 
@@ -330,10 +338,11 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     const DevScene& PS = P.scene;
     const DevCamera& cam = P.cam;
     const MatDev& atmo = P.atmo;
-    // per-lane column: node stack entries [0, stack_depth), leaf queue [stack_depth, stack_depth + RT_LQ);
+    // per-lane column: node stack entries [0, stack_depth), leaf queue [stack_depth, stack_depth + LQ);
     // entry e at s_stack[e * RT_BLOCK].  CULL builds keep the entry distance of each deferred
     // child in a second plane so that it can be re-culled when it is taken up.
-    const int n_ent = S.stack_depth + RT_LQ;
+    constexpr int LQ = RT_LQ_OF(SAH);
+    const int n_ent = S.stack_depth + LQ;
     int* s_stack = (int*)(s_mem + n_root4 + RT_PC_F4) + threadIdx.x;
     unsigned short* s_stack_t = (unsigned short*)((int*)(s_mem + n_root4 + RT_PC_F4) + (size_t)n_ent * RT_BLOCK) + threadIdx.x;
     int* s_leaf = s_stack + (size_t)S.stack_depth * RT_BLOCK;
@@ -378,7 +387,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
         // =============== traversal phase: node steps / triangle steps chosen by vote ===============
         while (true) {
             const bool has_leaf = tv.k >= 0 || tv.lq > 0;
-            const bool can_node = tv.node_live && tv.lq <= RT_LQ - 2;
+            const bool can_node = tv.node_live && tv.lq <= LQ - 2;
             if (mode == M_TRAV && !has_leaf && !tv.node_live) mode = M_PATH;   // the query is finished
             const uint64_t bN = __ballot(can_node), bT = __ballot(has_leaf);
             const int cN = __popcll(bN), cT = __popcll(bT), cAny = __popcll(bN | bT);

@@ -420,13 +420,13 @@ struct rt_ctx {
     int tlas_above = 32;                  // scenes with more meshes than this get the top-level tree (the LDS root mask holds 32)
     int accel = RT_ACCEL_REFERENCE;       // structure built by the next rt_set_scene (rt_set_accel)
     bool scene_is_sah = false;
-    int sah_leaf = 4;                     // triangles per SAH leaf (RT_SAH_LEAF)
+    int sah_leaf = 3;                     // triangles per SAH leaf (RT_SAH_LEAF); measured best with the 3-slot leaf queue
     int tlas_root = -1;                   // record of the top-level tree's root (scenes with > 32 meshes), else -1
     bool have_scene = false, have_cam = false, prep_pending = false;
     bool flags_pending = false;           // materials changed since the triangle flag words were written
     bool cull = false;                    // conservative distance culling (rt_set_cull)
     int node_bias = 0;
-    int burst8 = 4;
+    int burst8 = -1;                      // RT_BURST8; -1 = measured default (4 of 8 lanes, SAH scenes: 3 of 8)
     int recheck_all = 0;                  // RT_SAH_RECHECK_ALL: run the SAH structure's repeat path on every query (tests)
     int refill_below = 0;                 // lanes still traversing below which a wave shades/refills; 0 = measured default
     // camera / image
@@ -593,9 +593,9 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.n_by = (uint32_t)(c->cam.height + 15) / 16;
     a.n_chunks = 0;
     a.node_bias = c->node_bias;
-    a.burst8 = c->burst8;
+    a.burst8 = c->burst8 >= 0 ? c->burst8 : (c->scene_is_sah ? 3 : 4);
     a.recheck_all = c->recheck_all;
-    a.refill_below = c->refill_below > 0 ? c->refill_below : (c->cull ? 28 : 32);   // best measured, DESIGN.md 5
+    a.refill_below = c->refill_below > 0 ? c->refill_below : (!c->cull ? 32 : c->scene_is_sah ? 24 : 28);   // best measured, DESIGN.md 5
 }
 
 // dynamic LDS of a k_trace launch: root table + kernel-argument copy + per-lane node stack and leaf
@@ -611,21 +611,21 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     if (c->blocks_per_cu[key] <= 0) {
         int nb = 0, nb_best = 0;
         for (;;) {
-            HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, fixed + (size_t)(cap + RT_LQ) * per_ent));
+            HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, fixed + (size_t)(cap + RT_LQ_OF(SAH)) * per_ent));
             if (!DEEP || nb >= RT_WAVES || cap <= RT_MIN_STACK_LDS || c->stack_lds_force > 0) break;
             // lds_stack_entries guessed the allocation granule wrong, or registers are the limit
             if (nb_best == 0)
-                HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_best, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, fixed + (size_t)(RT_MIN_STACK_LDS + RT_LQ) * per_ent));
+                HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_best, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, fixed + (size_t)(RT_MIN_STACK_LDS + RT_LQ_OF(SAH)) * per_ent));
             if (nb >= nb_best) break;
             cap--;
         }
-        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (%d mesh roots)", fixed + (size_t)(cap + RT_LQ) * per_ent, c->n_meshes);
+        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (%d mesh roots)", fixed + (size_t)(cap + RT_LQ_OF(SAH)) * per_ent, c->n_meshes);
         c->blocks_per_cu[key] = nb;
         c->stack_lds[key] = cap;
-        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] k_trace variant %d: %d of %d node stack entries in LDS, %zu bytes of LDS, %d workgroups per CU\n", key, cap, c->stack_depth, fixed + (size_t)(cap + RT_LQ) * per_ent, nb);
+        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] k_trace variant %d: %d of %d node stack entries in LDS, %zu bytes of LDS, %d workgroups per CU\n", key, cap, c->stack_depth, fixed + (size_t)(cap + RT_LQ_OF(SAH)) * per_ent, nb);
     }
     cap = c->stack_lds[key];
-    const size_t lds = fixed + (size_t)(cap + RT_LQ) * per_ent;
+    const size_t lds = fixed + (size_t)(cap + RT_LQ_OF(SAH)) * per_ent;
     // every wave takes whole chunks: no point in more waves than chunks
     const unsigned grid = std::max(1u, (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_chunks + 3) / 4));
     TraceArgs b = a;
@@ -655,8 +655,9 @@ int lds_stack_entries(const rt_ctx* c) {
     const size_t per_ent = (size_t)RT_BLOCK * (c->cull ? 6 : 4);
     // LDS is handed out in 1280-byte granules on gfx950 (160 KB / 128): budget per workgroup rounded down to that
     const size_t budget = (c->lds_per_cu / RT_WAVES) / 1280 * 1280;
-    if (fixed + (size_t)(c->stack_depth + RT_LQ) * per_ent <= budget) return c->stack_depth;
-    const int fit = (int)((budget > fixed ? budget - fixed : 0) / per_ent) - RT_LQ;
+    const int lq = RT_LQ_OF(c->scene_is_sah);
+    if (fixed + (size_t)(c->stack_depth + lq) * per_ent <= budget) return c->stack_depth;
+    const int fit = (int)((budget > fixed ? budget - fixed : 0) / per_ent) - lq;
     return std::max(RT_MIN_STACK_LDS, std::min(c->stack_depth, fit));
 }
 
