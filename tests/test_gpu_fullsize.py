@@ -1,5 +1,7 @@
-"""Full BASELINE.json size (1920x1080, 64 passes, 4 bounces) checks on the GPU:
-first hit against the oracle, CULL against STRICT traversal, and size-independent properties."""
+"""Full BASELINE.json size (1920x1080, 64 passes, 4 bounces) checks on the GPU: the whole frame against
+the CPU oracle (6.4e8 queries, about 27 s of 16 CPU threads) in the exact mode and in the mode bench.py
+measures, first hit against the oracle, CULL against STRICT traversal, and size-independent properties.
+tests/full_size_oracle.py is the whole-frame check as a script (all modes, other configs)."""
 import numpy as np
 import pytest
 
@@ -70,3 +72,37 @@ def test_radiance_1080p_sample_rows_vs_oracle(oracle_lib, hip_lib):
     diff = int((a != b).any(axis=2).sum())
     print(f"1080p 1-pass radiance: {diff} of {W*H} pixels differ from the oracle")
     assert diff == 0
+
+
+PASSES, BOUNCES = 64, 4
+
+
+def _render(lib, sah, cull):
+    sc = build_suzanne(0)
+    c = lib.create()
+    c.set_accel(sah)
+    c.load_scene(sc)
+    c.load_camera(sc.cam)
+    c.resize(W, H)
+    c.set_cull(cull)
+    c.enable_stats(True)
+    ids, ts = c.first_hit(1)
+    c.render(1, PASSES, 1, 1, BOUNCES, 0)
+    out = ids, ts, c.read_mean(), c.stats()
+    c.close()
+    return out
+
+
+@pytest.mark.timeout(300)
+def test_bench_configuration_full_size_against_the_oracle(oracle_lib, hip_lib):
+    ref = _render(oracle_lib, False, False)
+    assert ref[3]["rays"] == 634615464 + W * H          # the 64 passes + the first-hit probe
+    for name, sah, cull in (("exact", False, False), ("SAH culled", True, True)):
+        r = _render(hip_lib, sah, cull)
+        assert np.array_equal(ref[0], r[0]), f"{name}: first-hit ids"
+        assert np.array_equal(ref[1].view(np.uint32), r[1].view(np.uint32)), f"{name}: first-hit distances"
+        assert np.array_equal(ref[2].view(np.uint32), r[2].view(np.uint32)), f"{name}: {(ref[2] != r[2]).any(axis=2).sum()} pixels differ"
+        for k in ("rays", "shaded_hits", "samples"):
+            assert ref[3][k] == r[3][k], (name, k)
+        if name == "exact":
+            assert ref[3]["tri_tests"] == r[3]["tri_tests"]
