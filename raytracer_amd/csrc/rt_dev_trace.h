@@ -271,8 +271,10 @@ struct Trav {
 // interior root the test is an exact shortcut: child boxes nest inside it and float
 // subtract/multiply are monotonic, so no child test could pass when the root test fails.
 template <bool STATS, bool CULL, bool FINITE>
-__device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn, v3 org, v3 inv, float best_t, bool sah, Counters& cnt) {
+__device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn, v3 org, v3 inv, float best_t, bool sah, Counters& cnt, int& nearest) {
     uint32_t mask = 0;
+    float near_t = 0.0f;
+    nearest = -1;
     const float mi = sah_slack(org, inv), mo = sah_org(org);
     // One box per trip, not unrolled: the kernel is issue bound, so overlapping the LDS latency
     // of several boxes buys nothing, while two or three boxes in flight cost spilled registers
@@ -298,17 +300,20 @@ __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn
             const bool take = real && h && !culled<CULL>(ta, tb, best_t);
             if (STATS) cnt.box += real;
             mask |= take ? (1u << (b0 + u)) : 0u;
+            const bool nearer = take && (nearest < 0 || ta < near_t);
+            nearest = nearer ? b0 + u : nearest;
+            near_t = nearer ? ta : near_t;
         }
     }
     return mask;
 }
 
 template <bool STATS, bool CULL>
-__device__ __forceinline__ uint32_t root_mask(int jn, const float4* s_roots, v3 org, v3 inv, float best_t, bool sah, Counters& cnt) {
+__device__ __forceinline__ uint32_t root_mask(int jn, const float4* s_roots, v3 org, v3 inv, float best_t, bool sah, Counters& cnt, int& nearest) {
     // wave-uniform choice of the slab-test form (see box_test_finite)
     const bool all_finite = __ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0;
-    return all_finite ? root_mask_loop<STATS, CULL, true>(s_roots, jn, org, inv, best_t, sah, cnt)
-                      : root_mask_loop<STATS, CULL, false>(s_roots, jn, org, inv, best_t, sah, cnt);
+    return all_finite ? root_mask_loop<STATS, CULL, true>(s_roots, jn, org, inv, best_t, sah, cnt, nearest)
+                      : root_mask_loop<STATS, CULL, false>(s_roots, jn, org, inv, best_t, sah, cnt, nearest);
 }
 
 // SAH structure: the reference only ever tests a triangle whose leaf box IN ITS OWN TREE the ray's
@@ -778,8 +783,14 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     tv.node_live = true;
                 } else {
                     tv.cur = RT_NONE;
-                    tv.mask = root_mask<STATS, CULL>(__builtin_amdgcn_readfirstlane(PS.n_meshes), s_roots, org, inv, tv.best_t, sah, cnt);
+                    int nearest;
+                    tv.mask = root_mask<STATS, CULL>(__builtin_amdgcn_readfirstlane(PS.n_meshes), s_roots, org, inv, tv.best_t, sah, cnt, nearest);
                     tv.node_live = tv.mask != 0;
+                    // the mesh whose root box the ray enters first is visited first (a hit there culls the others)
+                    if (nearest >= 0) {
+                        const int ref = __float_as_int(s_roots[2 * nearest].w);
+                        if (ref >= 0) { tv.cur = ref; tv.mask &= ~(1u << nearest); }
+                    }
                 }
                 mode = M_TRAV;
             }
