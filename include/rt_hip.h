@@ -167,6 +167,11 @@ int rt_bind_accum(rt_ctx* ctx, void* device_ptr);
 int rt_render(rt_ctx* ctx, uint32_t first_pass, uint32_t n_passes, uint32_t pass_stride,
               int rays_per_pixel, int max_bounces, int flags);
 
+/* replaces: the MAX_CYCLES uniform (application.py:132, 997): a pass whose index (frameNumber)
+ * is larger leaves the image as it is (raytracer.fs.glsl:931-935) - rt_render skips it.
+ * Default: no cap (0xffffffff); the Application mirror sets the reference's 2048*2048. */
+int rt_set_max_cycles(rt_ctx* ctx, uint32_t max_cycles);
+
 /* primary ray of sample 0 of `pass` per pixel: closest triangle id (-1 = miss; spheres
  * report -2-sphere_index) and distance (1e20 on a miss).  No reference counterpart: this is
  * the first-hit parity probe BASELINE.json asks for. */

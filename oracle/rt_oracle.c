@@ -34,6 +34,13 @@
  *   division so that the effect of this choice can be measured (tests/test_oracle_div.py).
  *   sin/cos/acos/exp/log are the fixed polynomial routines det_* below (GLSL leaves their
  *   precision to the driver).
+ * Variants (rto_set_variant, or RT_ORACLE_TRUE_DIV / RT_ORACLE_LIBM / RT_ORACLE_CARRY = 1 in the
+ * environment at rt_create): the same restatement under the OTHER admissible readings of the
+ * shader's text, so that the distance between them can be measured (tests/test_gpu_envelope.py,
+ * profiles/r02_envelope.txt): true division in the slab test (:425-442 as written), the C
+ * library's sinf/cosf/acosf/expf/logf in place of det_*, and the `doHitBackside` carry-over of
+ * :522, 605-610 in the reference's own traversal order (initial value false [9.6]).
+ * rto_first_hit_grazing marks the epsilon-grazing primary rays of SURVEY.md 9.7.
  * Decisions on undefined behaviour in the shader are those of SURVEY.md 9.6 and are marked
  * [9.6] where they apply.
  */
@@ -212,6 +219,9 @@ struct rt_ctx {
     float* accum_own; float* accum; uint64_t n_accum;
     rt_stats_t st;
     int true_div;
+    int libm;                                        /* variant: libm sinf/cosf/acosf/expf/logf instead of det_* */
+    int carry;                                       /* variant: doHitBackside carried across triangles (:522, 605-610) */
+    uint32_t max_cycles;                             /* MAX_CYCLES uniform (:46, 931-935) */
     int sum_mode;                                    /* last rt_render used RT_ACCUM_SUM */
     char err[256];
 };
@@ -228,6 +238,11 @@ int rt_create(int device, rt_ctx** out) {
     if (!c) return RT_E_NOMEM;
     const char* e = getenv("RT_ORACLE_TRUE_DIV");
     c->true_div = (e && e[0] == '1');
+    e = getenv("RT_ORACLE_LIBM");
+    c->libm = (e && e[0] == '1');
+    e = getenv("RT_ORACLE_CARRY");
+    c->carry = (e && e[0] == '1');
+    c->max_cycles = 0xffffffffu;
     *out = c;
     return RT_OK;
 }
@@ -332,6 +347,34 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
         int r = c->meshes[j].node0Id;
         if (r < 0 || r >= n_nodes) FAIL(c, RT_E_ARG, "mesh %d: bad root node", j);
         if (node_depth(c, r, 0) + 1 > RT_MAX_STACK) FAIL(c, RT_E_LIMIT, "mesh %d: BVH deeper than %d", j, RT_MAX_STACK - 1);
+    }
+    /* every triangle in at most one reachable leaf, and only in a tree of its own mesh (the
+     * product's rules, mirrored; the reference's builder guarantees both, chunker.py:216-244) */
+    {
+        char* listed = (char*)calloc((size_t)n_tris + 1, 1);
+        if (!listed) FAIL(c, RT_E_NOMEM, "out of memory");
+        int bad = 0, bad_tri = -1, bad_mesh = -1;
+        for (int j = 0; j < n_meshes && !bad; j++) {
+            int stack[RT_MAX_STACK + 2], sp = 0;
+            stack[sp++] = c->meshes[j].node0Id;
+            while (sp > 0 && !bad) {
+                const GraphNode* n = &c->nodes[stack[--sp]];
+                if (n->childId1 >= 0 || n->childId2 >= 0) {
+                    if (n->childId1 >= 0) stack[sp++] = n->childId1;
+                    if (n->childId2 >= 0) stack[sp++] = n->childId2;
+                    continue;
+                }
+                for (int i = 0; i < n->childObjCount && !bad; i++) {
+                    int t = c->leaf_ids[n->childObjOffset + i];
+                    if (c->tris[t].meshIndex != j) { bad = 1; bad_tri = t; bad_mesh = j; }
+                    else if (listed[t]) { bad = 2; bad_tri = t; }
+                    listed[t] = 1;
+                }
+            }
+        }
+        free(listed);
+        if (bad == 1) FAIL(c, RT_E_ARG, "triangle %d in the BVH of mesh %d belongs to mesh %d", bad_tri, bad_mesh, c->tris[bad_tri].meshIndex);
+        if (bad == 2) FAIL(c, RT_E_ARG, "triangle %d is listed in more than one leaf", bad_tri);
     }
     for (int j = 0; j < n_meshes; j++) refit_node(c, c->meshes[j].node0Id);
     c->have_scene = 1;
@@ -443,6 +486,7 @@ int rt_reset_accum(rt_ctx* c) {
 }
 int rt_bind_accum(rt_ctx* c, void* p) {
     if (!c) return RT_E_ARG;
+    if (c->w <= 0 || c->h <= 0 || (!p && !c->accum_own)) FAIL(c, RT_E_STATE, "no image size");
     c->accum = p ? (float*)p : c->accum_own;
     c->n_accum = 0;
     return RT_OK;
@@ -470,14 +514,19 @@ static inline float randomValue(uint32_t* s) {       /* :457-461 */
     return (float)x * 0x1p-32f;                      /* 4294967295.0 is 2^32 in float */
 }
 
-static inline v3 randomDirection(uint32_t* s) {      /* :478-492 */
+static inline v3 randomDirection(const rt_ctx* c, uint32_t* s) {      /* :478-492 */
     float u = randomValue(s);
     float v = randomValue(s);
     float theta = 6.2831855f * u;                    /* 2.0 * pi folded, pi = 3.14159265359 */
-    float phi = det_acos(2.0f * v - 1.0f);
     float sp, cp, st, ct;
-    det_sincos(phi, &sp, &cp);
-    det_sincos(theta, &st, &ct);
+    if (c && c->libm) {                              /* variant: the C library's functions */
+        float phi = acosf(2.0f * v - 1.0f);
+        sp = sinf(phi); cp = cosf(phi); st = sinf(theta); ct = cosf(theta);
+    } else {
+        float phi = det_acos(2.0f * v - 1.0f);
+        det_sincos(phi, &sp, &cp);
+        det_sincos(theta, &st, &ct);
+    }
     return V(sp * ct, sp * st, cp);
 }
 
@@ -575,6 +624,7 @@ static void calculateRayCollision(const rt_ctx* c, const Ray* ray, HitInfo* clos
     k->rays++;
     v3 inv = V(1.0f / ray->dir.x, 1.0f / ray->dir.y, 1.0f / ray->dir.z);
     HitInfo h;
+    int doHitBackside = 0;                           /* :522 uninitialised; false [9.6] (carry variant only) */
     for (int i = 0; i < c->n_spheres; i++) {
         raySphere(ray->origin, ray->dir, &c->spheres[i], &h);
         if (h.dst < 1e-6f) continue;
@@ -604,7 +654,12 @@ static void calculateRayCollision(const rt_ctx* c, const Ray* ray, HitInfo* clos
                 const Triangle* tri = &c->tris[c->leaf_ids[node->childObjOffset + i]];
                 if (tri->triId == ray->prevFacetId) continue;
                 int hitBehind;
-                if (ray->inSolid) hitBehind = (ray->prevMeshIndex == tri->meshIndex); /* [9.6] no carry-over */
+                if (c->carry) {                      /* variant: :605-615 as written, value carried across triangles */
+                    if (ray->inSolid) { if (ray->prevMeshIndex == tri->meshIndex) doHitBackside = 1; }
+                    else doHitBackside = !c->meshes[tri->meshIndex].material.transparentFromBehind;
+                    hitBehind = doHitBackside;
+                }
+                else if (ray->inSolid) hitBehind = (ray->prevMeshIndex == tri->meshIndex); /* [9.6] no carry-over */
                 else hitBehind = !c->meshes[tri->meshIndex].material.transparentFromBehind;
                 k->tri++;
                 rayTriangle(ray->origin, ray->dir, tri, hitBehind, &h);
@@ -646,7 +701,7 @@ static v3 traceRay(const rt_ctx* c, Ray* ray, uint32_t* rng, int maxBounces, Cou
         float n2 = (ray->inSolid && hit.hitBackside) ? c->atmosphere.ior : m->ior;
         float n1 = ray->ior;
         /* specularDir = refract(...) at :762 is overwritten on every path that reads it -> omitted */
-        v3 diffuseDir = normalize(add(neg(nrm), randomDirection(rng)));
+        v3 diffuseDir = normalize(add(neg(nrm), randomDirection(c, rng)));
         float costheta = clampf(dot(normalize(nrm), normalize(neg(ray->dir))), -1.0f, 1.0f);
         float r0 = (n1 - n2) / (n1 + n2);
         r0 = r0 * r0;                                /* pow(x,2) [9.6] */
@@ -662,8 +717,8 @@ static v3 traceRay(const rt_ctx* c, Ray* ray, uint32_t* rng, int maxBounces, Cou
         } else if (randomValue(rng) > schlick) {
             isSpecular = 0;
             if (randomValue(rng) < m->transmission) {
-                float a = -det_log(prevmat.transmission);
-                float e = det_exp(-a * hit.dst);
+                float a = c->libm ? -logf(prevmat.transmission) : -det_log(prevmat.transmission);
+                float e = c->libm ? expf(-a * hit.dst) : det_exp(-a * hit.dst);
                 v3 tc = scale(V(prevmat.color[0], prevmat.color[1], prevmat.color[2]), e);
                 rayColor = mul(rayColor, scale(tc, prevmat.color[3]));
                 if (hit.hitBackside) { ray->inSolid = 0; ray->ior = c->atmosphere.ior; }
@@ -730,7 +785,7 @@ static inline void newSampleRay(const rt_ctx* c, v3 viewPoint, uint32_t* rng, Ra
 static int ready(rt_ctx* c) {
     if (!c->have_scene) { snprintf(c->err, sizeof c->err, "no scene"); return 0; }
     if (!c->have_cam) { snprintf(c->err, sizeof c->err, "no camera"); return 0; }
-    if (!c->accum) { snprintf(c->err, sizeof c->err, "no image size"); return 0; }
+    if (!c->accum || c->w <= 0 || c->h <= 0) { snprintf(c->err, sizeof c->err, "no image size"); return 0; }
     return 1;
 }
 
@@ -740,6 +795,9 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
     if (rpp < 1 || maxBounces < 0 || stride < 1) FAIL(c, RT_E_ARG, "bad sampling arguments");
     if (flags != RT_ACCUM_MEAN && flags != RT_ACCUM_SUM) FAIL(c, RT_E_ARG, "bad flags");
     if (flags == RT_ACCUM_MEAN && stride != 1) FAIL(c, RT_E_ARG, "running mean needs pass_stride 1");
+    /* :931-935: frameNumber > MAX_CYCLES returns the previous frame */
+    if (first > c->max_cycles) n_passes = 0;
+    else { uint64_t m = ((uint64_t)c->max_cycles - first) / stride + 1; if (n_passes > m) n_passes = (uint32_t)m; }
     uint64_t rays = 0, box = 0, tri = 0, hits = 0;
     const int W = c->w, H = c->h;
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : rays, box, tri, hits)
@@ -778,6 +836,8 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
     return RT_OK;
 }
 
+int rt_set_max_cycles(rt_ctx* c, uint32_t m) { if (!c) return RT_E_ARG; c->max_cycles = m; return RT_OK; }
+
 int rt_first_hit(rt_ctx* c, uint32_t pass, int32_t* ids, float* ts) {
     if (!c || !ids || !ts) return RT_E_ARG;
     if (!ready(c)) return RT_E_STATE;
@@ -802,6 +862,92 @@ int rt_first_hit(rt_ctx* c, uint32_t pass, int32_t* ids, float* ts) {
     c->st.rays += rays; c->st.box_tests += box; c->st.tri_tests += tri;
     c->st.samples += (uint64_t)W * H;
     c->st.launches++;
+    return RT_OK;
+}
+
+/* Variant switches (see the header comment).  Negative = leave as it is. */
+int rto_set_variant(rt_ctx* c, int true_div, int libm, int carry) {
+    if (!c) return RT_E_ARG;
+    if (true_div >= 0) c->true_div = true_div != 0;
+    if (libm >= 0) c->libm = libm != 0;
+    if (carry >= 0) c->carry = carry != 0;
+    return RT_OK;
+}
+
+/* the primary ray of (pixel, pass) is epsilon-grazing iff
+ *   bit 0: another triangle (or sphere) is hit within |t2 - t1| <= 1e-5 * max(1, t1) of the winner,
+ *   bit 1: one of the three edge values N.C of the winning triangle has |N.C| <= 1e-6 * |N|^2,
+ *   bit 2: the winning triangle is met at |N.d| < 1e-5 * |N|.
+ * A pixel whose ray MISSES is grazing (bit 3) iff some triangle in a leaf the ray reaches is missed
+ * by an edge value that small (the neighbouring reading of the arithmetic could have hit it).
+ * mask_out = W*H bytes; `only` (may be NULL) = W*H bytes, pixels with 0 there are skipped (mask 0). */
+static int grazing_bits(const rt_ctx* c, const Ray* ray, const HitInfo* win) {
+    int bits = 0;
+    const float t1 = win->dst;
+    if (win->didHit && win->sphere < 0) {
+        const Triangle* tri = &c->tris[win->facetId];
+        v3 v0 = V(tri->posA[0], tri->posA[1], tri->posA[2]), v1 = V(tri->posB[0], tri->posB[1], tri->posB[2]);
+        v3 v2 = V(tri->posC[0], tri->posC[1], tri->posC[2]);
+        v3 N = cross(sub(v1, v0), sub(v2, v0));
+        float nn = dot(N, N), nd = dot(N, ray->dir);
+        v3 P = madd(ray->origin, t1, ray->dir);
+        float e0 = dot(N, cross(sub(v1, v0), sub(P, v0))), e1 = dot(N, cross(sub(v2, v1), sub(P, v1)));
+        float e2 = dot(N, cross(sub(v0, v2), sub(P, v2)));
+        if (fabsf(e0) <= 1e-6f * nn || fabsf(e1) <= 1e-6f * nn || fabsf(e2) <= 1e-6f * nn) bits |= 2;
+        if (fabsf(nd) < 1e-5f * sqrtf(nn)) bits |= 4;
+    }
+    HitInfo h;
+    const float tol = 1e-5f * fmaxf(1.0f, t1);
+    for (int i = 0; i < c->n_spheres; i++) {
+        if (win->didHit && win->sphere == i) continue;
+        raySphere(ray->origin, ray->dir, &c->spheres[i], &h);
+        if (h.didHit && !(h.dst < 1e-6f) && win->didHit && fabsf(h.dst - t1) <= tol) bits |= 1;
+    }
+    /* every triangle, whatever the boxes say: a near-tie hidden behind a box that one reading of
+     * the slab arithmetic passes and another fails is exactly what the mask is for */
+    for (int k = 0; k < c->n_tris; k++) {
+        const Triangle* tri = &c->tris[k];
+        if (win->didHit && win->sphere < 0 && tri->triId == win->facetId) continue;
+        int hitBehind = !c->meshes[tri->meshIndex].material.transparentFromBehind;   /* primary rays: not in a solid */
+        rayTriangle(ray->origin, ray->dir, tri, hitBehind, &h);
+        if (win->didHit) {
+            if (h.didHit && !(h.dst < 1e-6f) && fabsf(h.dst - t1) <= tol) bits |= 1;
+        } else {
+            /* a miss: would a slightly larger triangle have been hit? */
+            v3 v0 = V(tri->posA[0], tri->posA[1], tri->posA[2]), v1 = V(tri->posB[0], tri->posB[1], tri->posB[2]);
+            v3 v2 = V(tri->posC[0], tri->posC[1], tri->posC[2]);
+            v3 N = cross(sub(v1, v0), sub(v2, v0));
+            float nn = dot(N, N), nd = dot(N, ray->dir);
+            if (fabsf(nd) < 1e-6f || (nd > 0.0f && !hitBehind)) continue;
+            float t = -(dot(N, ray->origin) + (-dot(N, v0))) / nd;
+            if (!(t >= 1e-6f)) continue;
+            v3 P = madd(ray->origin, t, ray->dir);
+            float e0 = dot(N, cross(sub(v1, v0), sub(P, v0))), e1 = dot(N, cross(sub(v2, v1), sub(P, v1)));
+            float e2 = dot(N, cross(sub(v0, v2), sub(P, v2)));
+            const float lim = -1e-6f * nn;
+            if (e0 >= lim && e1 >= lim && e2 >= lim) bits |= 8;
+        }
+    }
+    return bits;
+}
+
+int rto_first_hit_grazing(rt_ctx* c, uint32_t pass, uint8_t* mask_out, const uint8_t* only) {
+    if (!c || !mask_out) return RT_E_ARG;
+    if (!ready(c)) return RT_E_STATE;
+    const int W = c->w, H = c->h;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int py = 0; py < H; py++) {
+        Counters k = {0, 0, 0, 0};
+        for (int px = 0; px < W; px++) {
+            if (only && !only[(size_t)py * W + px]) { mask_out[(size_t)py * W + px] = 0; continue; }
+            uint32_t rng = pixelSeed(c, px, py, pass);
+            Ray ray;
+            HitInfo h;
+            newSampleRay(c, viewPointOf(c, px, py), &rng, &ray);
+            calculateRayCollision(c, &ray, &h, &k);
+            mask_out[(size_t)py * W + px] = (uint8_t)grazing_bits(c, &ray, &h);
+        }
+    }
     return RT_OK;
 }
 
@@ -845,7 +991,7 @@ void* rt_stream(rt_ctx* c) { (void)c; return NULL; }
 
 /* single-function probes for the known-answer tests ------------------------------------ */
 float rto_random_value(uint32_t* state) { return randomValue(state); }
-void rto_random_direction(uint32_t* state, float out[3]) { v3 d = randomDirection(state); out[0] = d.x; out[1] = d.y; out[2] = d.z; }
+void rto_random_direction(uint32_t* state, float out[3]) { v3 d = randomDirection(NULL, state); out[0] = d.x; out[1] = d.y; out[2] = d.z; }
 int rto_box_hit(const float o[3], const float d[3], const float lo[3], const float hi[3], int true_div) {
     rt_ctx c; memset(&c, 0, sizeof c); c.true_div = true_div;
     v3 dd = V(d[0], d[1], d[2]);

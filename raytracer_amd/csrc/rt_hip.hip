@@ -399,6 +399,12 @@ struct rt_ctx {
     int stack_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // per k_trace variant: node stack entries in LDS for the scene in place
     DevBuf<int2> stack_ovf;               // deeper entries (rare): (stack_depth - cap) x launch lanes
     size_t stack_ovf_n = 0;
+    DevBuf<int32_t> fh_ids;               // rt_first_hit: device-side results (grow-only)
+    DevBuf<float> fh_ts;
+    DevBuf<float> tris_tmp;               // rt_read_tris28: gathered std140 image (grow-only)
+    MatDev* h_mats_pinned = nullptr;      // rt_set_materials: pinned staging of the 256 materials, guarded by mats_copied
+    hipEvent_t mats_copied = nullptr;
+    uint32_t max_cycles = 0xffffffffu;    // passes with a larger index leave the image as it is (raytracer.fs.glsl:931-935)
     int last_stack_lds = 0, last_lds_bytes = 0, last_blocks_per_cu = 0;   // layout of the most recent k_trace launch (rt_get_info)
     int tlas_rebuilds = 0;
     int stack_lds_force = 0;              // RT_STACK_LDS: LDS node stack entries, whatever the occupancy (tests of the deep-entry path)
@@ -535,7 +541,16 @@ int rebuild_tlas(rt_ctx* c) {
 }
 
 int run_prep(rt_ctx* c) {
-    if (!c->prep_pending) return RT_OK;
+    if (!c->prep_pending) {
+        // materials alone changed (rt_set_materials): only the triangles' flag words follow them -
+        // no pose upload, no host synchronisation, no refit
+        if (c->flags_pending && c->n_slots) {
+            hipLaunchKernelGGL(k_tri_flags, dim3(blocks_for(c->n_slots)), dim3(256), 0, c->stream, c->slot_mesh.p, c->mats.p, c->geo.p, c->n_slots);
+            HIPCK(c, hipGetLastError());
+        }
+        c->flags_pending = false;
+        return RT_OK;
+    }
     if (c->tlas_root >= 0 && c->tlas_pose_dirty && !c->tlas_static) {
         int rc = rebuild_tlas(c);                  // its copies complete at the synchronisation below
         if (rc) return rc;
@@ -627,11 +642,11 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     cap = c->stack_lds[key];
     const size_t lds = fixed + (size_t)(cap + RT_LQ_OF(SAH)) * per_ent;
     // every wave takes whole chunks: no point in more waves than chunks
-    const unsigned grid = std::max(1u, (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_chunks + 3) / 4));
+    unsigned grid = std::max(1u, (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_chunks + 3) / 4));
     TraceArgs b = a;
     b.scene.stack_depth = cap;
-    b.ovf_lanes = grid * RT_BLOCK;
-    const size_t need_ovf = (size_t)std::max(0, c->stack_depth - cap) * b.ovf_lanes;
+    const size_t deep = (size_t)std::max(0, c->stack_depth - cap);
+    const size_t need_ovf = deep * (size_t)grid * RT_BLOCK;
     if (c->stack_ovf_n < need_ovf) {
         HIPCK(c, hipStreamSynchronize(c->stream));
         c->stack_ovf.release();
@@ -640,10 +655,11 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
         c->stack_ovf_n = need_ovf;
     }
     b.stack_ovf = c->stack_ovf.p;
+    b.ovf_lanes = grid * RT_BLOCK;
     c->last_stack_lds = cap;
     c->last_lds_bytes = (int)lds;
     c->last_blocks_per_cu = c->blocks_per_cu[key];
-    HIPCK(c, hipMemsetAsync(c->work_counter.p, 0, sizeof(unsigned int), c->stream));
+    HIPCK(c, hipMemsetAsync(b.work_counter, 0, sizeof(unsigned int), c->stream));
     hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST, SAH, DEEP>), dim3(grid), dim3(RT_BLOCK), lds, c->stream, b);
     return RT_OK;
 }
@@ -688,9 +704,26 @@ int launch_trace(rt_ctx* c, const TraceArgs& a, bool first_hit) {
 int check_ready(rt_ctx* c) {
     if (!c->have_scene) return fail(c, RT_E_STATE, "no scene");
     if (!c->have_cam) return fail(c, RT_E_STATE, "no camera");
-    if (!c->accum) return fail(c, RT_E_STATE, "no image size");
+    if (!c->accum || c->cam.width <= 0 || c->cam.height <= 0) return fail(c, RT_E_STATE, "no image size");
     return RT_OK;
 }
+
+// The pair of events around one trace launch.  Destroyed on every path that does not hand them to
+// note_launch (an error between creation and the hand-over must not leak them).
+struct LaunchTimer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool handed = false;
+    hipError_t create() {
+        hipError_t e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        return e;
+    }
+    ~LaunchTimer() {
+        if (handed) return;
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
 
 // Fold the event pairs whose launches have already finished into kernel_ms without blocking, so
 // that a long render loop which never asks for statistics does not pile up events.
@@ -754,7 +787,12 @@ int rt_create(int device, rt_ctx** out) {
     }
     if (c->n_cus <= 0) c->n_cus = 256;
     if (c->work_counter.alloc(1) != hipSuccess || c->counters.alloc(16) != hipSuccess ||
-        hipMemsetAsync(c->counters.p, 0, 128, c->stream) != hipSuccess) {
+        hipMemsetAsync(c->counters.p, 0, 128, c->stream) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_mats_pinned, 256 * sizeof(MatDev), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&c->mats_copied, hipEventDisableTiming) != hipSuccess) {
+        if (c->h_mats_pinned) (void)hipHostFree(c->h_mats_pinned);
+        c->work_counter.release();
+        c->counters.release();
         (void)hipStreamDestroy(c->own_stream);
         delete c;
         return RT_E_DEVICE;
@@ -782,6 +820,11 @@ int rt_destroy(rt_ctx* c) {
     c->work_counter.release();
     c->stack_ovf.release();
     c->counters.release();
+    c->fh_ids.release();
+    c->fh_ts.release();
+    c->tris_tmp.release();
+    if (c->h_mats_pinned) (void)hipHostFree(c->h_mats_pinned);
+    if (c->mats_copied) (void)hipEventDestroy(c->mats_copied);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RT_OK;
@@ -830,9 +873,11 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     std::vector<int> first_visit;
     int max_depth = 0;
     // walks the trees `wn` (roots `wroot[j]`, leaf lists in `wids`) and fills the vectors above
+    std::vector<char> listed;              // triangle already met in a leaf of this walk
     auto walk = [&](const Std140Node* wn, int wn_count, const int32_t* wids, const std::vector<int>& wroot) -> int {
         vnodes.clear(); vdepth.clear(); vnode_id.clear(); pack.clear(); rest.clear();
         slot_mesh.clear(); slot_rem.clear(); slot_id.clear();
+        listed.assign((size_t)n_tris, 0);
         first_visit.assign(wn_count, -1);
         max_depth = 0;
         const size_t visit_cap = 4 * (size_t)wn_count + 16;
@@ -860,6 +905,10 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
                         const Std140Tri& t = tris[wids[n.off + i]];
                         if (t.meshIndex != j)
                             return fail(c, RT_E_ARG, "triangle %d in the BVH of mesh %d belongs to mesh %d", t.triId, j, t.meshIndex);
+                        // the reference's builder puts every triangle into exactly one leaf (chunker.py:216-244);
+                        // a second listing would make rank and triId disagree for the previous-hit skip (:600)
+                        if (listed[t.triId]) return fail(c, RT_E_ARG, "triangle %d is listed in more than one leaf", t.triId);
+                        listed[t.triId] = 1;
                         const float* src[6] = {t.posA, t.posB, t.posC, t.nA, t.nB, t.nC};
                         for (int q = 0; q < 6; q++) rest.push_back(make_float4(src[q][0], src[q][1], src[q][2], 0.f));
                         slot_mesh.push_back(j);
@@ -1048,13 +1097,16 @@ int rt_set_materials(rt_ctx* c, const void* meshes128, int n_meshes, const void*
     if (n_meshes != c->n_meshes || !meshes128) return fail(c, RT_E_ARG, "mesh count mismatch");
     HIPCK(c, hipSetDevice(c->device));
     const Std140Mesh* meshes = (const Std140Mesh*)meshes128;
-    std::vector<MatDev> mats(n_meshes);
-    for (int j = 0; j < n_meshes; j++) mats[j] = meshes[j].material;
-    if (n_meshes) HIPCK(c, hipMemcpyAsync(c->mats.p, mats.data(), (size_t)n_meshes * 80, hipMemcpyHostToDevice, c->stream));
+    // pinned staging, so that the copy is stream-ordered and the host does not wait for the device
+    // (the previous copy out of the staging buffer has normally long finished)
+    HIPCK(c, hipEventSynchronize(c->mats_copied));
+    for (int j = 0; j < n_meshes; j++) c->h_mats_pinned[j] = meshes[j].material;
+    if (n_meshes) {
+        HIPCK(c, hipMemcpyAsync(c->mats.p, c->h_mats_pinned, (size_t)n_meshes * 80, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipEventRecord(c->mats_copied, c->stream));
+    }
     if (atmosphere80) std::memcpy(&c->atmo, atmosphere80, 80);
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    c->flags_pending = true;     // transparentFromBehind lives in the triangles' flag words
-    c->prep_pending = true;
+    c->flags_pending = true;     // transparentFromBehind lives in the triangles' flag words: k_tri_flags before the next launch
     return RT_OK;
 }
 
@@ -1084,15 +1136,17 @@ int rt_read_tris28(rt_ctx* c, float* out) {
     int rc = run_prep(c);
     if (rc) return rc;
     // static part (padding, mesh index, id) on the host, posed part gathered on the device
-    DevBuf<float> tmp;
-    HIPCK(c, tmp.alloc(28 * (size_t)std::max(c->n_tris, 1)));
+    DevBuf<float>& tmp = c->tris_tmp;
+    if (tmp.n < 28 * (size_t)std::max(c->n_tris, 1)) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        HIPCK(c, tmp.alloc(28 * (size_t)std::max(c->n_tris, 1)));
+    }
     HIPCK(c, hipMemsetAsync(tmp.p, 0, 28 * (size_t)std::max(c->n_tris, 1) * 4, c->stream));
     if (c->n_slots)
         hipLaunchKernelGGL(k_gather_tris28, dim3(blocks_for(c->n_slots)), dim3(256), 0, c->stream, c->geo.p, c->nrm.p,
                            c->slot_id.p, c->n_slots, tmp.p, c->n_tris);
     hipError_t e = hipMemcpyAsync(out, tmp.p, 28 * (size_t)c->n_tris * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    tmp.release();
     if (e != hipSuccess) return fail(c, RT_E_DEVICE, "read_tris28: %s", hipGetErrorString(e));
     // ids and mesh indices: slot tables are authoritative
     std::vector<int> sm(c->n_slots), si(c->n_slots);
@@ -1165,7 +1219,7 @@ int rt_reset_accum(rt_ctx* c) {
 
 int rt_bind_accum(rt_ctx* c, void* p) {
     if (!c) return RT_E_ARG;
-    if (!p && !c->accum_own.p) return fail(c, RT_E_STATE, "no image size");
+    if (c->cam.width <= 0 || c->cam.height <= 0 || (!p && !c->accum_own.p)) return fail(c, RT_E_STATE, "no image size");
     c->accum = p ? (float*)p : c->accum_own.p;
     c->n_accum = 0;
     return RT_OK;
@@ -1185,6 +1239,9 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
     if (rpp < 1 || max_bounces < 0 || stride < 1) return fail(c, RT_E_ARG, "bad sampling arguments");
     if (flags != RT_ACCUM_MEAN && flags != RT_ACCUM_SUM) return fail(c, RT_E_ARG, "bad flags");
     if (flags == RT_ACCUM_MEAN && stride != 1) return fail(c, RT_E_ARG, "running mean needs pass_stride 1");
+    // raytracer.fs.glsl:931-935: a pass whose index exceeds MAX_CYCLES returns the previous frame
+    if (first > c->max_cycles) n_passes = 0;
+    else n_passes = (uint32_t)std::min<uint64_t>(n_passes, ((uint64_t)c->max_cycles - first) / stride + 1);
     HIPCK(c, hipSetDevice(c->device));
     if ((rc = run_prep(c))) return rc;
     TraceArgs a;
@@ -1208,21 +1265,27 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
         a.first_pass = first + done * stride;
         a.n_passes = std::min(chunk, n_passes - done);
         a.n_chunks = a.n_passes * a.n_bx * a.n_by;
-        hipEvent_t e0, e1;
-        HIPCK(c, hipEventCreate(&e0));
-        HIPCK(c, hipEventCreate(&e1));
-        HIPCK(c, hipEventRecord(e0, c->stream));
+        LaunchTimer t;
+        HIPCK(c, t.create());
+        HIPCK(c, hipEventRecord(t.e0, c->stream));
         if ((rc = launch_trace(c, a, false))) return rc;
-        HIPCK(c, hipEventRecord(e1, c->stream));
-        note_launch(c, e0, e1);
+        HIPCK(c, hipEventRecord(t.e1, c->stream));
+        note_launch(c, t.e0, t.e1);
+        t.handed = true;
         c->st.launches++;
-        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, c->stream, c->totals.p, c->accum,
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, c->stream, a.totals, c->accum,
                            (size_t)n_px, a.first_pass, a.n_passes, stride, rpp, a.sum_mode);
     }
     HIPCK(c, hipGetLastError());
     c->n_accum += n_passes;
     c->sum_mode = (flags == RT_ACCUM_SUM);
     c->st.samples += per_pass * n_passes;
+    return RT_OK;
+}
+
+int rt_set_max_cycles(rt_ctx* c, uint32_t max_cycles) {
+    if (!c) return RT_E_ARG;
+    c->max_cycles = max_cycles;
     return RT_OK;
 }
 
@@ -1233,14 +1296,18 @@ int rt_first_hit(rt_ctx* c, uint32_t pass, int32_t* ids, float* ts) {
     HIPCK(c, hipSetDevice(c->device));
     if ((rc = run_prep(c))) return rc;
     const size_t n = (size_t)c->cam.width * c->cam.height;
-    DevBuf<int32_t> d_ids;
-    DevBuf<float> d_ts;
-    HIPCK(c, d_ids.alloc(n));
-    if (d_ts.alloc(n) != hipSuccess) { d_ids.release(); return fail(c, RT_E_DEVICE, "first_hit: out of device memory"); }
+    if (c->fh_ids.n < n || c->fh_ts.n < n) {               // grow-only device-side results
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (c->fh_ids.alloc(n) != hipSuccess || c->fh_ts.alloc(n) != hipSuccess) {
+            c->fh_ids.release();
+            c->fh_ts.release();
+            return fail(c, RT_E_NOMEM, "first_hit: out of device memory");
+        }
+    }
     TraceArgs a;
     fill_args(c, a);
-    a.ids = d_ids.p;
-    a.ts = d_ts.p;
+    a.ids = c->fh_ids.p;
+    a.ts = c->fh_ts.p;
     a.first_pass = pass;
     a.n_passes = 1;
     a.pass_stride = 1;
@@ -1248,23 +1315,21 @@ int rt_first_hit(rt_ctx* c, uint32_t pass, int32_t* ids, float* ts) {
     a.max_bounces = 0;
     a.sum_mode = 0;
     a.n_chunks = a.n_bx * a.n_by;
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, c->stream);
-    rc = launch_trace(c, a, true);
-    if (rc) { d_ids.release(); d_ts.release(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
-    (void)hipEventRecord(e1, c->stream);
-    note_launch(c, e0, e1);
+    {
+        LaunchTimer t;
+        HIPCK(c, t.create());
+        HIPCK(c, hipEventRecord(t.e0, c->stream));
+        if ((rc = launch_trace(c, a, true))) return rc;
+        HIPCK(c, hipEventRecord(t.e1, c->stream));
+        note_launch(c, t.e0, t.e1);
+        t.handed = true;
+    }
     c->st.launches++;
     c->st.samples += n;
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(ids, d_ids.p, n * 4, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ts, d_ts.p, n * 4, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    d_ids.release();
-    d_ts.release();
-    if (e != hipSuccess) return fail(c, RT_E_DEVICE, "first_hit: %s", hipGetErrorString(e));
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(ids, c->fh_ids.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(ts, c->fh_ts.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 

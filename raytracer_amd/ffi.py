@@ -68,6 +68,7 @@ _SIGNATURES = {
     "rt_reset_accum": (C.c_int, [_vp]),
     "rt_bind_accum": (C.c_int, [_vp, _vp]),
     "rt_render": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]),
+    "rt_set_max_cycles": (C.c_int, [_vp, C.c_uint32]),
     "rt_first_hit": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "rt_read_accum": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64)]),
     "rt_read_mean": (C.c_int, [_vp, _vp]),
@@ -241,6 +242,10 @@ class RtContext:
             self.lib.dll.rt_render(self._h, first_pass, n_passes, pass_stride, rays_per_pixel, max_bounces, flags),
             "rt_render",
         )
+
+    def set_max_cycles(self, max_cycles: int) -> None:
+        """MAX_CYCLES uniform (application.py:997): passes with a larger index leave the image unchanged."""
+        self._ck(self.lib.dll.rt_set_max_cycles(self._h, int(max_cycles) & 0xFFFFFFFF), "rt_set_max_cycles")
 
     def first_hit(self, pass_index: int = 1) -> tuple[np.ndarray, np.ndarray]:
         ids = np.empty((self.height, self.width), dtype=np.int32)

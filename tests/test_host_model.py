@@ -163,6 +163,11 @@ def check_error_codes(lib, suzanne):
     one_mesh["node0Id"] = 0
     tri0 = b["tris28"][:1].copy()
     expect(-4, ctx.set_scene, tri0, one_mesh, deep, np.zeros(1, np.int32), None, b["atmosphere80"])
+    # a triangle listed in two leaves (the reference's builder never does that, chunker.py:216-244)
+    bad = b["leaf_tri_ids"].copy()
+    bad[1] = bad[0]
+    assert "more than one leaf" in expect(-1, ctx.set_scene, *args(leaf_tri_ids=bad))
+    expect(-2, ctx.bind_accum, 12345)                             # no image size yet: nothing to bind to
     ctx.set_scene(*args())
     expect(-1, ctx.update_mesh_pose, 99, [0, 0, 0], [0, 0, 0, 1])
     expect(-2, ctx.render, 1, 1, 1, 1, 1, 0)                       # no camera
@@ -177,9 +182,18 @@ def check_error_codes(lib, suzanne):
     expect(-1, ctx.render, 1, 2, 1, 1, 1, 7)                       # unknown flags
     ctx.render(1, 2, 1, 1, 1, 0)                                   # and after all that the context still works
     assert np.isfinite(ctx.read_mean()).all()
+    # MAX_CYCLES (raytracer.fs.glsl:931-935): passes beyond it leave the image as it is
+    img2 = ctx.read_mean()
+    ctx.set_max_cycles(2)
+    ctx.render(3, 4, 1, 1, 1, 0)
+    assert np.array_equal(ctx.read_mean().view(np.uint32), img2.view(np.uint32)) and ctx.read_accum()[1] == 2
+    ctx.reset_accum()
+    ctx.render(1, 5, 1, 1, 1, 0)                                   # passes 1, 2 count; 3, 4, 5 do not
+    assert np.array_equal(ctx.read_mean().view(np.uint32), img2.view(np.uint32)) and ctx.read_accum()[1] == 2
+    ctx.set_max_cycles(0xFFFFFFFF)
     ctx.close()
     return codes
 
 
 def test_error_codes(oracle_lib, suzanne):
-    assert len(check_error_codes(oracle_lib, suzanne)) == 16
+    assert len(check_error_codes(oracle_lib, suzanne)) == 18
