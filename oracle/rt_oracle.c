@@ -836,6 +836,10 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
     return RT_OK;
 }
 
+/* the product's allocation-free variant renders the same image; the oracle has nothing to allocate */
+int rt_render_static(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int rpp, int maxBounces, int flags) {
+    return rt_render(c, first, n_passes, stride, rpp, maxBounces, flags);
+}
 int rt_set_max_cycles(rt_ctx* c, uint32_t m) { if (!c) return RT_E_ARG; c->max_cycles = m; return RT_OK; }
 
 int rt_first_hit(rt_ctx* c, uint32_t pass, int32_t* ids, float* ts) {

@@ -237,6 +237,19 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES) void k_trace(TraceArgs a) {
     trace_pixels<STATS, CULL, FIRST_HIT, SAH, DEEP>(a, s_mem);
 }
 
+// Scratch of rt_render_static, the entry point that allocates nothing (include/rt_hip.h): the work
+// counter, the node stack entries beyond the LDS ones and the per-(pass, pixel) radiance of one
+// launch live in this file-scope array instead of hipMalloc'ed buffers.  Every GPU the library
+// runs on holds its own copy until the process ends; its DEVICE address is taken once per context
+// with hipGetSymbolAddress (rt_create) - in host code the name `scratch` is only a stand-in.
+//   [0, 256)                                 work counter
+//   [256, 256 + RT_STATIC_OVF_BYTES)         stack_ovf (int2 per deep entry and launch lane)
+//   [256 + RT_STATIC_OVF_BYTES, end)         totals (float3 per (pass, pixel) of the launch in flight)
+#define RT_STATIC_OVF_BYTES ((size_t)16 << 20)
+#define RT_STATIC_TOTALS_OFF ((size_t)256 + RT_STATIC_OVF_BYTES)
+static_assert(RT_STATIC_SCRATCH_BYTES > RT_STATIC_TOTALS_OFF + (1u << 20), "scratch layout");
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
 // ----------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------
@@ -399,6 +412,8 @@ struct rt_ctx {
     int stack_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // per k_trace variant: node stack entries in LDS for the scene in place
     DevBuf<int2> stack_ovf;               // deeper entries (rare): (stack_depth - cap) x launch lanes
     size_t stack_ovf_n = 0;
+    unsigned char* static_scratch = nullptr;   // device address of `scratch` on this context's GPU (hipGetSymbolAddress)
+    bool launch_static = false;           // the launch in preparation belongs to rt_render_static: nothing may be allocated
     DevBuf<int32_t> fh_ids;               // rt_first_hit: device-side results (grow-only)
     DevBuf<float> fh_ts;
     DevBuf<float> tris_tmp;               // rt_read_tris28: gathered std140 image (grow-only)
@@ -646,15 +661,25 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     TraceArgs b = a;
     b.scene.stack_depth = cap;
     const size_t deep = (size_t)std::max(0, c->stack_depth - cap);
-    const size_t need_ovf = deep * (size_t)grid * RT_BLOCK;
-    if (c->stack_ovf_n < need_ovf) {
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        c->stack_ovf.release();
-        c->stack_ovf_n = 0;
-        HIPCK(c, c->stack_ovf.alloc(need_ovf));
-        c->stack_ovf_n = need_ovf;
+    if (c->launch_static) {
+        // rt_render_static: the deep entries live in the static scratch; a scene whose deep entries
+        // do not fit for a full grid runs on as many workgroups as they fit for
+        const size_t cap_ent = RT_STATIC_OVF_BYTES / sizeof(int2);
+        if (deep * RT_BLOCK > cap_ent) return fail(c, RT_E_LIMIT, "rt_render_static: BVH too deep for the static scratch (%zu entries per lane beyond LDS)", deep);
+        if (deep) grid = (unsigned)std::min<size_t>(grid, cap_ent / (deep * RT_BLOCK));
+        b.stack_ovf = (int2*)(c->static_scratch + 256);
+        b.work_counter = (unsigned int*)c->static_scratch;
+    } else {
+        const size_t need_ovf = deep * (size_t)grid * RT_BLOCK;
+        if (c->stack_ovf_n < need_ovf) {
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            c->stack_ovf.release();
+            c->stack_ovf_n = 0;
+            HIPCK(c, c->stack_ovf.alloc(need_ovf));
+            c->stack_ovf_n = need_ovf;
+        }
+        b.stack_ovf = c->stack_ovf.p;
     }
-    b.stack_ovf = c->stack_ovf.p;
     b.ovf_lanes = grid * RT_BLOCK;
     c->last_stack_lds = cap;
     c->last_lds_bytes = (int)lds;
@@ -786,8 +811,11 @@ int rt_create(int device, rt_ctx** out) {
         if (prop.maxSharedMemoryPerMultiProcessor > 0) c->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
     }
     if (c->n_cus <= 0) c->n_cus = 256;
+    // this GPU's copy of the static scratch (each device holds its own, at its own address)
+    void* sp = nullptr;
     if (c->work_counter.alloc(1) != hipSuccess || c->counters.alloc(16) != hipSuccess ||
         hipMemsetAsync(c->counters.p, 0, 128, c->stream) != hipSuccess ||
+        hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)) != hipSuccess || !sp ||
         hipHostMalloc((void**)&c->h_mats_pinned, 256 * sizeof(MatDev), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&c->mats_copied, hipEventDisableTiming) != hipSuccess) {
         if (c->h_mats_pinned) (void)hipHostFree(c->h_mats_pinned);
@@ -797,6 +825,7 @@ int rt_create(int device, rt_ctx** out) {
         delete c;
         return RT_E_DEVICE;
     }
+    c->static_scratch = (unsigned char*)sp;
     *out = c;
     return RT_OK;
 }
@@ -1232,7 +1261,8 @@ int rt_set_accum_passes(rt_ctx* c, uint64_t n) {
     return RT_OK;
 }
 
-int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int rpp, int max_bounces, int flags) {
+// rt_render and rt_render_static: same launches, other homes for the launch's scratch
+static int render_impl(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int rpp, int max_bounces, int flags, bool use_static) {
     if (!c) return RT_E_ARG;
     int rc = check_ready(c);
     if (rc) return rc;
@@ -1254,33 +1284,58 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
     // per-(pass, pixel) radiance buffer stays below 1.6 GB); k_accumulate then folds them in order
     const uint64_t n_px = (uint64_t)c->cam.width * c->cam.height;
     const uint64_t per_pass = n_px * (uint64_t)rpp;
-    const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (1ull << 27) / std::max<uint64_t>(per_pass, 1));
-    const uint32_t most = std::min(chunk, n_passes);
-    if (c->totals.n < (size_t)most * n_px * 3) {
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        if (c->totals.alloc((size_t)most * n_px * 3) != hipSuccess) return fail(c, RT_E_NOMEM, "no device memory for %u passes of radiance", most);
+    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (1ull << 27) / std::max<uint64_t>(per_pass, 1));
+    if (use_static) {
+        // the radiance of a launch must fit the static scratch: nothing is allocated on this path
+        const uint64_t fit = (RT_STATIC_SCRATCH_BYTES - RT_STATIC_TOTALS_OFF) / (n_px * 12);
+        if (fit < 1)
+            return fail(c, RT_E_LIMIT, "rt_render_static: image of %llu pixels exceeds the %llu pixels one pass may have in the %u MiB static scratch",
+                        (unsigned long long)n_px, (unsigned long long)((RT_STATIC_SCRATCH_BYTES - RT_STATIC_TOTALS_OFF) / 12), (unsigned)(RT_STATIC_SCRATCH_BYTES >> 20));
+        chunk = (uint32_t)std::min<uint64_t>(chunk, fit);
+        a.totals = (float*)(c->static_scratch + RT_STATIC_TOTALS_OFF);
+    } else {
+        const uint32_t most = std::min(chunk, n_passes);
+        if (c->totals.n < (size_t)most * n_px * 3) {
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            if (c->totals.alloc((size_t)most * n_px * 3) != hipSuccess) return fail(c, RT_E_NOMEM, "no device memory for %u passes of radiance", most);
+        }
+        a.totals = c->totals.p;
     }
-    a.totals = c->totals.p;
+    c->launch_static = use_static;
     for (uint32_t done = 0; done < n_passes; done += chunk) {
         a.first_pass = first + done * stride;
         a.n_passes = std::min(chunk, n_passes - done);
         a.n_chunks = a.n_passes * a.n_bx * a.n_by;
-        LaunchTimer t;
-        HIPCK(c, t.create());
-        HIPCK(c, hipEventRecord(t.e0, c->stream));
-        if ((rc = launch_trace(c, a, false))) return rc;
-        HIPCK(c, hipEventRecord(t.e1, c->stream));
-        note_launch(c, t.e0, t.e1);
-        t.handed = true;
+        if (use_static) {                              // no events either: creating one may allocate
+            rc = launch_trace(c, a, false);
+            if (rc) { c->launch_static = false; return rc; }
+        } else {
+            LaunchTimer t;
+            HIPCK(c, t.create());
+            HIPCK(c, hipEventRecord(t.e0, c->stream));
+            if ((rc = launch_trace(c, a, false))) return rc;
+            HIPCK(c, hipEventRecord(t.e1, c->stream));
+            note_launch(c, t.e0, t.e1);
+            t.handed = true;
+        }
         c->st.launches++;
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, c->stream, a.totals, c->accum,
                            (size_t)n_px, a.first_pass, a.n_passes, stride, rpp, a.sum_mode);
     }
+    c->launch_static = false;
     HIPCK(c, hipGetLastError());
     c->n_accum += n_passes;
     c->sum_mode = (flags == RT_ACCUM_SUM);
     c->st.samples += per_pass * n_passes;
     return RT_OK;
+}
+
+int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int rpp, int max_bounces, int flags) {
+    return render_impl(c, first, n_passes, stride, rpp, max_bounces, flags, false);
+}
+
+int rt_render_static(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int rpp, int max_bounces, int flags) {
+    return render_impl(c, first, n_passes, stride, rpp, max_bounces, flags, true);
 }
 
 int rt_set_max_cycles(rt_ctx* c, uint32_t max_cycles) {

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "rt_reset_accum": (C.c_int, [_vp]),
     "rt_bind_accum": (C.c_int, [_vp, _vp]),
     "rt_render": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]),
+    "rt_render_static": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]),
     "rt_set_max_cycles": (C.c_int, [_vp, C.c_uint32]),
     "rt_first_hit": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "rt_read_accum": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64)]),
@@ -241,6 +242,14 @@ class RtContext:
         self._ck(
             self.lib.dll.rt_render(self._h, first_pass, n_passes, pass_stride, rays_per_pixel, max_bounces, flags),
             "rt_render",
+        )
+
+    def render_static(self, first_pass: int, n_passes: int, pass_stride: int = 1, rays_per_pixel: int = 1,
+                      max_bounces: int = 1, flags: int = RT_ACCUM_MEAN) -> None:
+        """rt_render without any allocation: scratch in the library's static device array (rt_hip.h)."""
+        self._ck(
+            self.lib.dll.rt_render_static(self._h, first_pass, n_passes, pass_stride, rays_per_pixel, max_bounces, flags),
+            "rt_render_static",
         )
 
     def set_max_cycles(self, max_cycles: int) -> None:

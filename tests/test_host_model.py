@@ -180,6 +180,7 @@ def check_error_codes(lib, suzanne):
     expect(-1, ctx.render, 1, 2, 1, 0, 1, 0)                       # rays_per_pixel < 1
     expect(-1, ctx.render, 1, 2, 1, 1, -1, 0)                      # negative bounces
     expect(-1, ctx.render, 1, 2, 1, 1, 1, 7)                       # unknown flags
+    expect(-1, ctx.render_static, 1, 2, 3, 1, 1, 0)                # the allocation-free variant checks the same way
     ctx.render(1, 2, 1, 1, 1, 0)                                   # and after all that the context still works
     assert np.isfinite(ctx.read_mean()).all()
     # MAX_CYCLES (raytracer.fs.glsl:931-935): passes beyond it leave the image as it is
@@ -196,4 +197,4 @@ def check_error_codes(lib, suzanne):
 
 
 def test_error_codes(oracle_lib, suzanne):
-    assert len(check_error_codes(oracle_lib, suzanne)) == 18
+    assert len(check_error_codes(oracle_lib, suzanne)) == 19
