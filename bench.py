@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py - Mrays/s of the rendering hot path on BASELINE.json configs[1]:
-Suzanne room, 1920x1080, 64 spp as 64 passes x 1 ray/pixel, 4 bounces, one MI355X.
+"""bench.py - Mrays/s of the rendering hot path.
 
-A "step" = one full render of that frame (one persistent k_trace launch over all 64 passes plus
-one k_accumulate launch; scene and accumulator resident in HBM).  ray = one closest-hit query (calculateRayCollision,
-shaders/raytracer.fs.glsl:518-641 of the reference), counted exactly in-kernel by a
-separate counting launch of the same deterministic work.
+Default workload = BASELINE.json configs[1]: Suzanne room, 1920x1080, 64 spp as 64 passes x
+1 ray/pixel, 4 bounces, one MI355X.  `--workload subdiv4k` = configs[3] (Suzanne subdivided to
+991 316 triangles, 3840x2160, 256 passes), `--workload dragon` = configs[4] (the 192-mesh dragon
+scene, 1080p, 64 passes, 8 bounces); the driver's line stays on the default.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling - every rank renders
-64 passes of the same frame with its own pass indices (rank r takes 1+r, 1+r+N, ...), i.e.
-64*N spp in total, into a SUM accumulator; one RCCL all-reduce per step combines them
-(the exchange step the path really has).
+A "step" = one full render of that frame (persistent k_trace launches over all passes plus the
+k_accumulate launches that fold them; scene and accumulator resident in HBM).  ray = one
+closest-hit query (calculateRayCollision, shaders/raytracer.fs.glsl:518-641 of the reference),
+counted exactly in-kernel by a separate counting launch of the same deterministic work.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU), `--scaling`:
+  weak   (default) every rank renders all PASSES of the frame with its own pass indices (rank r
+         takes 1+r, 1+r+N, ...), i.e. PASSES*N spp in total, into a SUM accumulator;
+  strong the frame's PASSES are split over the ranks (raytracer_amd.distributed.shard_passes):
+         fixed total work, what "x-times faster at N GPUs" means (north_star: >= 7x at 8 GPUs on
+         the 4K spp-sharded config = `--workload subdiv4k --scaling strong`);
+both with one RCCL all-reduce of the W*H*3 float32 sum per step (the exchange the path really has,
+SURVEY.md 8(e)).
 
 Prints ONE JSON line on rank 0.
 """
@@ -19,6 +27,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -26,13 +35,19 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-WIDTH, HEIGHT, PASSES, RPP, BOUNCES = 1920, 1080, 64, 1, 4
+# the BASELINE.json configurations that fit one GPU: scene recipe, image, sampling, default steps, CPU sample
+WORKLOADS = {
+    "suzanne1080": dict(config="configs[1]", scene="suzanne", what="Suzanne room (1052 triangles, 9 meshes)",
+                        width=1920, height=1080, passes=64, rpp=1, bounces=4, steps=20, cpu_passes=20, cpu_size=(1920, 1080)),
+    "subdiv4k": dict(config="configs[3]", scene="suzanne5", what="Suzanne subdivided 5x (991 316 triangles) in the room",
+                     width=3840, height=2160, passes=256, rpp=1, bounces=4, steps=2, cpu_passes=4, cpu_size=(1920, 1080)),
+    "dragon": dict(config="configs[4]", scene="dragon", what="dragon scene (192 meshes, 12 658 triangles, glossy/emissive)",
+                   width=1920, height=1080, passes=64, rpp=1, bounces=8, steps=20, cpu_passes=16, cpu_size=(1920, 1080)),
+}
 # RT_BENCH_REHEARSAL=1: a tiny frame, ONLY to walk the N > 1 code path with several ranks sharing one
 # GPU (two full-size persistent kernels time-slice pathologically there); its line says so and is
 # not a measurement
 REHEARSAL = os.environ.get("RT_BENCH_REHEARSAL", "0") == "1"
-if REHEARSAL:
-    WIDTH, HEIGHT, PASSES = 320, 180, 4
 # algorithmic work per unit (DESIGN.md "roofline accounting")
 FLOP_BOX, FLOP_TRI, FLOP_HIT = 27, 47, 160
 BYTE_BOX, BYTE_TRI, BYTE_HIT = 32, 36, 48
@@ -40,16 +55,40 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X FP32 vector peak (= dense f32 MFMA peak), MI
 PEAK_HBM_GBS = 8000.0
 
 
+def build_scene(which: str, lib=None):
+    from raytracer_amd.scripts.scenes import final_scene_numba as S
+
+    if which == "dragon":
+        from raytracer_amd.scripts.scenes import dragon_scene as D
+
+        sc = D.build()
+    elif which.startswith("suzanne") and which != "suzanne":
+        sc = S.build(subdivide=int(which[7:]), lib=lib)          # BVH of the 991 316 triangles by rt_bvh_build
+    else:
+        sc = S.build()
+    sc.animate_frame(0)
+    return sc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: per workload, a few seconds of GPU time)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="suzanne1080")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-passes", type=int, default=20, help="passes of the CPU baseline sample (20 = about 15 s on 16 threads)")
+    ap.add_argument("--cpu-passes", type=int, default=None, help="passes of the CPU baseline sample (default per workload: about 10-20 s on 16 threads)")
     ap.add_argument("--strict", action="store_true", help="visit exactly the reference's box set (no distance culling)")
     ap.add_argument("--reference-structure", action="store_true", help="traverse the reference's own BVH instead of the SAH one")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the untimed legs on the reference's own BVH (profiling runs)")
     args = ap.parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    if REHEARSAL:
+        wl.update(width=320, height=180, passes=4)
+    WIDTH, HEIGHT, PASSES, RPP, BOUNCES = wl["width"], wl["height"], wl["passes"], wl["rpp"], wl["bounces"]
+    if args.steps is None:
+        args.steps = wl["steps"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -59,12 +98,18 @@ def main() -> None:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
 
-    import numpy as np
+    # The CPU baseline leg runs FIRST (rank 0, N = 1 only), before anything touches the GPU: the GPU
+    # legs then form one contiguous stretch at the end of the process, which is what a sampler of GPU
+    # activity (rocm-smi every few seconds) needs to see them.
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(wl, args.cpu_passes if args.cpu_passes is not None else wl["cpu_passes"])
+
     import torch
     import torch.distributed as dist
 
     from raytracer_amd import ffi
-    from raytracer_amd.scripts.scenes import final_scene_numba as S
+    from raytracer_amd.distributed import shard_passes
 
     # RT_BENCH_BACKEND=gloo + fewer GPUs than ranks is a rehearsal of the N > 1 code path on a
     # one-GPU box (ranks share the card); the real run is nccl (= RCCL), one GPU per rank
@@ -86,9 +131,8 @@ def main() -> None:
             dist.barrier()
 
     # ---- scene + context (inputs resident in HBM before the timed region) ----
-    scene = S.build()
-    scene.animate_frame(0)
     lib = ffi.RtLib()                      # hand-written HIP kernels; raises if missing
+    scene = build_scene(wl["scene"], lib)
     ctx = lib.create(local_rank)
     # the opt-in SAH structure (same triangles, reference ranks for ties) + distance culling: the
     # fastest mode whose image is bit-identical to the reference structure's exact traversal on this
@@ -104,14 +148,21 @@ def main() -> None:
     ctx.bind_accum(accum.data_ptr())
 
     sum_mode = world > 1
-    first_pass, stride = (1 + rank, world) if sum_mode else (1, 1)
+    if not sum_mode:
+        first_pass, n_passes, stride, total_passes = 1, PASSES, 1, PASSES
+    elif args.scaling == "weak":
+        first_pass, n_passes, stride, total_passes = 1 + rank, PASSES, world, PASSES * world
+    else:
+        first_pass, n_passes, stride = shard_passes(PASSES, rank, world)
+        total_passes = PASSES
 
     def step():
         ctx.reset_accum()
-        ctx.render(first_pass, PASSES, stride, RPP, BOUNCES, ffi.RT_ACCUM_SUM if sum_mode else ffi.RT_ACCUM_MEAN)
+        if n_passes:
+            ctx.render(first_pass, n_passes, stride, RPP, BOUNCES, ffi.RT_ACCUM_SUM if sum_mode else ffi.RT_ACCUM_MEAN)
         if sum_mode:
             dist.all_reduce(accum)         # RCCL over xGMI; same stream as the render
-            ctx.set_accum_passes(PASSES * world)
+            ctx.set_accum_passes(total_passes)
 
     # ---- counting launch: exact rays / box tests / triangle tests / hits of one step ----
     ctx.enable_stats(True)
@@ -146,29 +197,30 @@ def main() -> None:
 
     # ---- dominant kernel: average launch duration by HIP events on the launch stream ----
     st = ctx.stats()
+    info = ctx.info()
     launches = max(int(st["launches"]), 1)
     kern_ms = st["kernel_ms"] / launches
+    per_step = max(1, launches // max(args.steps, 1))            # k_trace launches one step needs (2^27 samples each at most)
     # per-launch algorithmic work of THIS rank (rank 0 reports its own kernel)
-    flop_launch = (FLOP_BOX * counts["box_tests"] + FLOP_TRI * counts["tri_tests"] + FLOP_HIT * counts["shaded_hits"])
-    # bytes the traversal touches (served by L1/L2: the whole scene is 130 KB) ...
-    byte_launch = BYTE_BOX * counts["box_tests"] + BYTE_TRI * counts["tri_tests"] + BYTE_HIT * counts["shaded_hits"]
+    flop_launch = (FLOP_BOX * counts["box_tests"] + FLOP_TRI * counts["tri_tests"] + FLOP_HIT * counts["shaded_hits"]) / per_step
+    # bytes the traversal touches, as if every fetch went to memory ...
+    byte_launch = (BYTE_BOX * counts["box_tests"] + BYTE_TRI * counts["tri_tests"] + BYTE_HIT * counts["shaded_hits"]) / per_step
     # ... and the only stream that has to reach HBM: one float3 per (pixel, pass), folded by k_accumulate
-    hbm_launch = 12.0 * WIDTH * HEIGHT * PASSES
-    flop_launch /= max(1, launches // max(args.steps, 1))
-    byte_launch /= max(1, launches // max(args.steps, 1))
-    hbm_launch /= max(1, launches // max(args.steps, 1))
+    hbm_launch = 12.0 * WIDTH * HEIGHT * n_passes / per_step
     achieved_tflops = flop_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
     achieved_gbs = hbm_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     cache_gbs = byte_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
-    traffic = None
+    # HBM bytes per launch from the PMC passes of THIS command line (tools/prof_bench.sh; counters cannot be
+    # read from inside the process): profiles/pmc_latest.json holds them per workload, with their provenance
+    traffic, traffic_source = None, None
     pmc = ROOT / "profiles" / "pmc_latest.json"
-    if pmc.exists():
+    if pmc.exists() and not args.strict and not args.reference_structure and not REHEARSAL:
         try:
-            rec = json.loads(pmc.read_text())
-            # the counters were collected on the default mode's kernel: no figure for the others
-            if not args.strict and not args.reference_structure:
+            rec = json.loads(pmc.read_text()).get(args.workload)
+            if rec:
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = {k: rec.get(k) for k in ("file", "commit", "command", "correction")}
         except Exception:
             traffic = None
 
@@ -177,7 +229,7 @@ def main() -> None:
     # for the record: the same frame on the reference's own BVH, culled and exact (rt_set_cull(0));
     # not the headline (the headline mode renders the identical image)
     other = None
-    if world == 1 and not args.strict and not args.reference_structure:
+    if world == 1 and not args.strict and not args.reference_structure and not args.no_other_modes and args.workload == "suzanne1080":
         def timed2():
             step()
             torch.cuda.synchronize(dev)
@@ -196,13 +248,14 @@ def main() -> None:
         ctx.set_cull(False)
         other["exact_box_set"] = timed2()
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_passes)
-
     if rank == 0:
+        deep = info["stack_entries_lds"] < info["stack_entries"]
+        kernel = "k_trace<STATS=false,CULL=%s,FIRST_HIT=false,SAH=%s,DEEP=%s>" % (
+            "false" if args.strict else "true", "false" if args.reference_structure else "true", "true" if deep else "false")
+        hbm_frac = (traffic / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if (traffic and kern_ms > 0) else None
         out = {
-            "metric": "Mrays/sec, Suzanne 1080p (rays = closest-hit queries, counted in-kernel)",
+            "metric": "Mrays/sec, Suzanne 1080p (rays = closest-hit queries, counted in-kernel)" if args.workload == "suzanne1080"
+                      else f"Mrays/sec, {args.workload} (rays = closest-hit queries, counted in-kernel)",
             "value": round(value, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -210,41 +263,46 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic: Suzanne room from the reference's OBJ assets, camera = keyframe 0, RNG seeds = pass 1..64",
+            "data": f"synthetic: {wl['what']} from the reference's OBJ assets, camera = keyframe 0, RNG seeds = pass 1..{total_passes}",
             "config": {
-                "workload": f"configs[1]: Suzanne {WIDTH}x{HEIGHT}, {PASSES} spp ({PASSES} passes x {RPP} ray/px), "
-                            f"{BOUNCES} bounces, per GPU",
+                "workload": f"{wl['config']}: {wl['what']}, {WIDTH}x{HEIGHT}, {PASSES} spp ({PASSES} passes x {RPP} ray/px), "
+                            f"{BOUNCES} bounces" + (", per GPU" if args.scaling == "weak" else ", whole job"),
                 "structure": "reference BVH" if args.reference_structure else "SAH over the same triangles, reference tie ranks (bit-identical image)",
                 "traversal": "strict (reference box set)" if args.strict else "distance-culled (bit-identical image)",
                 "parallelism": "1 GPU, running mean" if world == 1 else
-                               f"spp-sharded x{world} (pass stride {world}) + RCCL all-reduce of the {WIDTH*HEIGHT*12/1e6:.1f} MB sum",
+                               (f"spp-sharded x{world}, {args.scaling} scaling (rank r renders passes r+1, r+1+{world}, ...: {n_passes} on rank 0) "
+                                f"+ RCCL all-reduce of the {WIDTH*HEIGHT*12/1e6:.1f} MB sum"),
                 "rays_per_step": int(rays_step),
                 "box_tests_per_ray": round(box_step / rays_step, 2),
                 "tri_tests_per_ray": round(tri_step / rays_step, 2),
                 "hits_per_ray": round(hit_step / rays_step, 3),
+                "k_trace_launches_per_step": per_step,
+                "node_stack_entries": [info["stack_entries_lds"], info["stack_entries"]],
             },
             "roofline": {
                 "bound": "mfma",
-                "engine": "f32 VALU (no GEMM shape on this path; the f32 vector-FMA peak equals the dense f32 MFMA peak)",
-                "kernel": "k_trace<STATS=false,CULL=%s,FIRST_HIT=false,SAH=%s,DEEP=false>" % ("false" if args.strict else "true", "false" if args.reference_structure else "true"),
+                "engine": "f32 VALU issue (no MFMA instruction is issued: no GEMM shape on this path; the contract's 'mfma' stands for the "
+                          "arithmetic roofline, priced at the f32 vector-FMA peak = the dense f32 MFMA peak)",
+                "kernel": kernel,
                 "achieved": round(achieved_tflops, 3),
                 "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved_tflops / PEAK_FP32_TFLOPS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "avg_launch_ms": round(kern_ms, 3),
                 "flop_per_launch": int(flop_launch),
                 "hbm": {"achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(achieved_gbs / PEAK_HBM_GBS, 4),
+                        "measured_frac": None if hbm_frac is None else round(hbm_frac, 4),
                         "algorithmic_bytes_per_launch": int(hbm_launch),
                         "note": "the per-(pixel, pass) radiance stream, 12 B per sample: the only data that must reach HBM; "
-                                "not the bound of this kernel"},
+                                "measured_frac = roofline.traffic / launch time / peak; not the bound of this kernel"},
                 "cache": {"node_triangle_bytes_per_launch": int(byte_launch), "rate_GBps": round(cache_gbs, 1),
-                          "note": "32 B/box test + 36 B/triangle test + 48 B/hit (SURVEY.md 8d), served by L1/L2: "
-                                  "the scene is 130 KB"},
+                          "note": "32 B/box test + 36 B/triangle test + 48 B/hit (SURVEY.md 8d), served by L1/L2 (Infinity Cache for subdiv4k)"},
             },
             "cpu_baseline": cpu,
             "reference_structure": other,
@@ -257,34 +315,47 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(passes: int) -> dict:
-    """The CPU oracle (a port: the reference has no CPU renderer) on a bounded sample of the
-    same workload: same scene/camera/seeds, the first `passes` of the 64 passes on all the
-    threads OpenMP gives us, and pass 1 alone on one thread."""
+def cpu_baseline(wl: dict, passes: int) -> dict:
+    """The CPU oracle (a port: the reference has no CPU renderer) on a bounded sample of the same
+    workload: same scene/camera/seeds, the first `passes` passes on all the threads OpenMP gives us,
+    and pass 1 alone on one thread at a quarter of the pixels.  Runs in a child
+    process so that nothing of it (OpenMP pool, 1 GB of scene copies) stays in the GPU process."""
+    code = (
+        "import json,sys,time,os\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import bench\n"
+        "print(json.dumps(bench._cpu_baseline_child(json.loads(sys.argv[1]), int(sys.argv[2]))))\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code, json.dumps(wl), str(passes)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("cpu_baseline child failed:\n" + r.stderr[-2000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def _cpu_baseline_child(wl: dict, passes: int) -> dict:
     from raytracer_amd import ffi
-    from raytracer_amd.scripts.scenes import final_scene_numba as S
 
     lib = ffi.RtLib(ROOT / "oracle" / "librt_oracle.so")
     lib.dll.rto_set_threads.restype = int
     threads = int(lib.dll.rto_set_threads(int(os.environ.get("OMP_NUM_THREADS", "0") or 0)))
-    scene = S.build()
-    scene.animate_frame(0)
+    scene = build_scene(wl["scene"], lib)
     ctx = lib.create(0)
     ctx.load_scene(scene)
     ctx.load_camera(scene.cam)
-    ctx.resize(WIDTH, HEIGHT)
+    W, H = wl["cpu_size"]
+    ctx.resize(W, H)
 
     def timed(n_passes):
         ctx.reset_stats()
         ctx.reset_accum()
         t0 = time.perf_counter()
-        ctx.render(1, n_passes, 1, RPP, BOUNCES, ffi.RT_ACCUM_MEAN)
+        ctx.render(1, n_passes, 1, wl["rpp"], wl["bounces"], ffi.RT_ACCUM_MEAN)
         dt = time.perf_counter() - t0
         return ctx.stats()["rays"], dt
 
     rays, dt = timed(passes)
     lib.dll.rto_set_threads(1)
-    ctx.resize(WIDTH // 2, HEIGHT // 2)            # a quarter of the pixels keeps the scalar run to seconds
+    ctx.resize(W // 2, H // 2)                     # a quarter of the pixels keeps the scalar run to seconds
     rays1, dt1 = timed(1)
     lib.dll.rto_set_threads(threads)
     ctx.close()
@@ -293,10 +364,10 @@ def cpu_baseline(passes: int) -> dict:
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"oracle/rt_oracle.c (OpenMP), same scene/camera/seeds, {WIDTH}x{HEIGHT}, passes 1..{passes} of {PASSES}, "
-                  f"{BOUNCES} bounces: {rays} rays in {dt:.2f} s",
+        "sample": f"oracle/rt_oracle.c (OpenMP), same scene/camera/seeds, {W}x{H}, passes 1..{passes} of {wl['passes']}, "
+                  f"{wl['bounces']} bounces: {rays} rays in {dt:.2f} s",
         "single_thread": {"value": round(rays1 / dt1 / 1e6, 3), "unit": "Mrays/s", "cores": 1,
-                          "sample": f"pass 1 at {WIDTH // 2}x{HEIGHT // 2}: {rays1} rays in {dt1:.2f} s"},
+                          "sample": f"pass 1 at {W // 2}x{H // 2}: {rays1} rays in {dt1:.2f} s"},
     }
 
 

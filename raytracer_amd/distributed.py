@@ -73,3 +73,156 @@ class ShardedRenderer:
 
     def mean_numpy(self, total_passes: int) -> np.ndarray:
         return (self.accum / float(total_passes)).cpu().numpy()
+
+
+class ShardedAnimation:
+    """Frame-sharded rendering of a keyframe animation (BASELINE.json configs[2]): rank r of n
+    animates and renders frames r, r+n, ... through the reference's own call path -
+    ``Application.animate_frame`` -> ``RayTracerDynamic.calculate_frame`` (application.py:390-394,
+    1151-1223) - on its own GPU.  A frame is a pure function of its index (``get_frame_number`` +
+    ``Scene.animate_frame``, application.py:1167-1172), so there is no data-path collective; finished
+    frames are written by the rank that rendered them and can be gathered to rank 0, one round of n
+    frames at a time (bounded memory).
+
+    ``scene_module`` must expose ``scene`` and ``get_frame_number`` like the reference's scene modules.
+    """
+
+    def __init__(self, scene_module, width: int, height: int, lib: ffi.RtLib | None = None, device: int = 0, group=None,
+                 cull: bool = False, sah: bool = False, save_frames: bool = False, export_root="renders/RayTracerDynamic"):
+        from .scripts import application as A
+
+        self.A = A
+        self.group = group
+        try:
+            import torch.distributed as dist
+
+            self.dist = dist if dist.is_initialized() else None
+        except ImportError:                      # single process without torch
+            self.dist = None
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+        A.set_scene(scene_module)
+        self.app = A.Application.__new__(A.Application)
+        self.prog = A.RayTracerDynamic.__new__(A.RayTracerDynamic)
+        A.RayTracerDynamic.__init__(self.prog, self.app, file_vertex_shader="shaders/raytracer.vs.glsl",
+                                    file_fragment_shader="shaders/raytracer.fs.glsl", width=width, height=height, lib=lib,
+                                    device=device, save_frames=save_frames, export_root=export_root, cull=cull, sah=sah)
+        A.Application.__init__(self.app, render_height=height, max_frames=None, program=self.prog)
+        self.prog.configure_program(self.app.display_scene)
+        self.width, self.height = width, height
+
+    def render_frame(self, frame: int) -> np.ndarray:
+        """One animation frame through the program's own per-frame entry (the counter is pre-set so that
+        ``app_frame_counter += 1`` lands on `frame`, application.py:1167-1169)."""
+        self.prog.app_frame_counter = frame - 1
+        self.prog.calculate_frame(self.app.display_scene)
+        return self.prog.last_image
+
+    def run(self, n_frames: int, gather: bool = False, first_frame: int = 0, on_frame=None) -> dict:
+        """Render frames first_frame .. first_frame+n_frames-1, sharded round-robin.  Returns {frame:
+        image} of this rank's frames; with ``gather`` rank 0 returns every frame (other ranks their own).
+        ``on_frame(frame, image)`` is called on the rank that holds the image (rank 0 when gathering)."""
+        mine = [first_frame + f for f in frames_of_rank(n_frames, self.rank, self.world)]
+        out = {}
+        rounds = (n_frames + self.world - 1) // self.world
+        for k in range(rounds):
+            img = None
+            if k < len(mine):
+                img = self.render_frame(mine[k])
+                out[mine[k]] = img
+                if on_frame is not None and not (gather and self.world > 1):
+                    on_frame(mine[k], img)
+            if gather and self.world > 1:
+                got = self._gather_round(img)
+                if self.rank == 0:
+                    for r, g in enumerate(got):
+                        f = first_frame + k * self.world + r
+                        if f < first_frame + n_frames:
+                            out[f] = g
+                            if on_frame is not None:
+                                on_frame(f, g)
+        return out
+
+    def _gather_round(self, img):
+        import torch
+
+        on_gpu = self.dist.get_backend(self.group) == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        t = torch.zeros((self.height, self.width, 3), dtype=torch.float32, device=dev)
+        if img is not None:
+            t.copy_(torch.from_numpy(np.ascontiguousarray(img)))
+        bufs = [torch.empty_like(t) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(t, bufs, dst=0, group=self.group)
+        return [b.cpu().numpy() for b in bufs] if self.rank == 0 else None
+
+    def close(self) -> None:
+        if self.prog.ctx is not None:
+            self.prog.ctx.close()
+            self.prog.ctx = None
+
+
+def main(argv=None) -> None:
+    """configs[2] runner: ``python -m torch.distributed.run --nproc-per-node N -m raytracer_amd.distributed
+    --frames 250 --height 1080 --passes 64`` renders the keyframe animation of final_scene_numba, frames sharded
+    over the ranks (one GPU each), and prints one JSON line with the whole-job frame rate on rank 0."""
+    import argparse
+    import json
+    import os
+    import time
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=250)
+    ap.add_argument("--first-frame", type=int, default=0)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--passes", type=int, default=64)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--save", action="store_true", help="write PNG/EXR/.npy of every frame at the reference's cadence")
+    ap.add_argument("--gather", action="store_true", help="collect the finished frames on rank 0")
+    ap.add_argument("--reference-structure", action="store_true")
+    a = ap.parse_args(argv)
+
+    import types
+
+    import torch
+    import torch.distributed as dist
+
+    from .scripts.animate import FrameAnimation
+    from .scripts.scenes import final_scene_numba as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    sc = S.build()
+
+    def override(cam, i):
+        cam.passes_per_frame, cam.bounces_per_ray = a.passes, a.bounces
+
+    sc.animations.append(FrameAnimation(sc.cam, override))
+    mod = types.SimpleNamespace(scene=sc, get_frame_number=S.get_frame_number, __file__=S.__file__)
+    anim = ShardedAnimation(mod, a.height * 16 // 9, a.height, device=local, cull=True, sah=not a.reference_structure,
+                            save_frames=a.save)
+    anim.render_frame(a.first_frame)                 # warm-up: first launch, allocations
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = anim.run(a.frames, gather=a.gather, first_frame=a.first_frame)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if anim.rank == 0:
+        print(json.dumps({"metric": "animation frames/s (configs[2]: keyframes of final_scene_numba, frames sharded over the ranks)",
+                          "value": round(a.frames / dt, 3), "unit": "frames/s", "n_gpus": world, "frames": a.frames,
+                          "frames_held_by_rank0": len(got), "seconds": round(dt, 3),
+                          "config": {"workload": f"{a.height * 16 // 9}x{a.height}, {a.passes} passes x 1 ray/px, {a.bounces} bounces per frame, "
+                                                 "host animate hooks + device pose/refit + render + read-back"}}), flush=True)
+    anim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

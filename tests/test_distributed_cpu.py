@@ -68,3 +68,72 @@ def test_spp_sharding_world2_gloo(tmp_path, oracle_lib):
     tol = 1e-5 * max(1.0, float(running_mean.max()))
     assert np.abs(m0 - single_sum_mean).max() <= tol
     assert np.abs(m0 - running_mean).max() <= tol
+
+
+# ---- frame sharding: BASELINE.json configs[2] ------------------------------------------------------
+FRAMES, AW, AH, APASSES, ABOUNCES = 5, 32, 18, 3, 4
+
+
+def _anim_module():
+    import types
+
+    from raytracer_amd.scripts.animate import FrameAnimation
+    from raytracer_amd.scripts.scenes import final_scene_numba as S
+
+    sc = S.build()
+
+    def override(cam, i):
+        cam.passes_per_frame, cam.bounces_per_ray = APASSES, ABOUNCES
+
+    sc.animations.append(FrameAnimation(sc.cam, override))
+    return types.SimpleNamespace(scene=sc, get_frame_number=S.get_frame_number, __file__=S.__file__)
+
+
+def _anim_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+
+    from conftest import ORACLE_SO
+    from raytracer_amd.distributed import ShardedAnimation
+    from raytracer_amd.ffi import RtLib
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    anim = ShardedAnimation(_anim_module(), AW, AH, lib=RtLib(ORACLE_SO))
+    got = anim.run(FRAMES, gather=True, first_frame=40)
+    np.savez(Path(out_dir) / f"frames_{rank}.npz", **{str(f): img for f, img in got.items()})
+    anim.close()
+    dist.destroy_process_group()
+
+
+def test_frame_sharding_world2_gloo(tmp_path, oracle_lib):
+    """rank r animates and renders frames 40+r, 40+r+2, ... through Application.animate_frame /
+    calculate_frame; the union (gathered to rank 0) equals the single-process frames bit for bit."""
+    import torch.multiprocessing as mp
+
+    from raytracer_amd.distributed import ShardedAnimation
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_anim_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "frames_0.npz"), np.load(tmp_path / "frames_1.npz")
+    assert sorted(int(k) for k in r0.files) == [40, 41, 42, 43, 44]          # rank 0 holds every frame after the gather
+    assert sorted(int(k) for k in r1.files) == [41, 43]                      # rank 1 rendered (and keeps) the odd ones
+    single = ShardedAnimation(_anim_module(), AW, AH, lib=oracle_lib)
+    ref = single.run(FRAMES, first_frame=40)
+    single.close()
+    assert sorted(ref) == [40, 41, 42, 43, 44]
+    for f in ref:
+        assert ref[f].max() > 0
+        assert np.array_equal(ref[f].view(np.uint32), r0[str(f)].view(np.uint32)), f"frame {f} differs"
+    for f in (41, 43):
+        assert np.array_equal(r1[str(f)].view(np.uint32), r0[str(f)].view(np.uint32))
+    assert not np.array_equal(ref[40], ref[44])                               # the animation moves
+    # and a frame rendered out of order equals the same frame rendered in sequence (frame purity, application.py:1167-1172)
+    from conftest import build_suzanne, make_ctx
+
+    c = make_ctx(oracle_lib, build_suzanne(43), AW, AH)
+    c.render(1, APASSES, 1, 1, ABOUNCES, 0)
+    assert np.array_equal(c.read_mean().view(np.uint32), ref[43].view(np.uint32))
