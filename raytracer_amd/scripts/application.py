@@ -224,6 +224,27 @@ def read_exr(path) -> np.ndarray:
     return out
 
 
+def tone_map(color):
+    """Reinhard operator of the reference's export helpers (application.py:1463-1465; the same expression sits
+    commented out in shaders/toScreen.fs.glsl:18-21 and raytracer.fs.glsl:919-922).  color: H x W x 3 or 4."""
+    return color / (color + 1.0)
+
+
+def gamma_correct(color, gamma=2.2):
+    """application.py:1467-1468 (toScreen.fs.glsl:23-26).  Nothing on the live path applies either of the two
+    (application.py:1104-1117 clips the raw mean); they are hooks for the caller."""
+    return np.power(color, 1.0 / gamma)
+
+
+def to_display(hdr, gamma=2.2):
+    """What the reference's commented-out display pass would show (toScreen.fs.glsl:28-38):
+    tone-mapped, gamma-corrected, 8-bit."""
+    with np.errstate(invalid="ignore"):
+        t = tone_map(np.maximum(hdr, 0.0))
+    t = np.where(np.isnan(t), 1.0, t)                 # inf / (inf + 1): infinite radiance shows as white
+    return (np.clip(gamma_correct(t, gamma), 0.0, 1.0) * 255).astype(np.uint8)
+
+
 class ProgramABC(ABC):
     """Plugin interface of a render program (application.py:475-611)."""
 
@@ -267,12 +288,13 @@ class RayTracerDynamic(ProgramABC):
     def __init__(self, app: Application, file_vertex_shader: str, file_fragment_shader: str, width: int, height: int,
                  standalone=not HEADLESS, require=460, lib: ffi.RtLib | None = None, device: int = 0,
                  save_frames: bool = True, export_root: str | Path = "renders/RayTracerDynamic", cull: bool = False,
-                 sah: bool = False) -> None:
+                 sah: bool = False, display_png: bool = False) -> None:
         self._lib = lib                       # tests inject a checker library; the product loads the HIP one
         self._device = device
         self.save_frames = save_frames
         self.cull = cull                      # distance culling: same image, fewer box tests
         self.sah = sah                        # traverse the library's SAH tree over the same triangles: same image
+        self.display_png = display_png        # also write the tone-mapped + gamma-corrected frame (`_tm.png`, to_display)
         self.export_root = Path(export_root)
         self.MAX_RAY_BOUNCES = 8
         self.RAYS_PER_PIXEL = 32
@@ -317,6 +339,7 @@ class RayTracerDynamic(ProgramABC):
             recs[i]["index"] = m.id
             recs[i]["material"] = m.material.as_record()
         self.ctx.set_materials(recs, scene.atmosphere_material.as_record().reshape(1))
+        self.ctx.set_max_cycles(self.app.MAX_CYCLES)      # program["MAX_CYCLES"] (application.py:997)
         self.app.is_animating = True
         if not hasattr(self, "app_frame_counter"):
             self.app_frame_counter = 0
@@ -372,6 +395,8 @@ class RayTracerDynamic(ProgramABC):
         np.save(self.target_dir / f"{stem}_f4.npy", flipped)
         write_pfm(self.target_dir / f"{stem}_f4.pfm", hdr)
         write_exr(self.target_dir / f"{stem}_f4.exr", flipped)
+        if self.display_png:
+            Image.fromarray(to_display(flipped), "RGB").save(self.target_dir / f"{stem}_tm.png")
 
     def handle_event(self, event, app, cam, scene, keyboard_enabled, mouse_enabled):
         return

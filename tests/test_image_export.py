@@ -5,6 +5,7 @@ format's published structure (magic, version, attribute table, offset table, per
 import struct
 
 import numpy as np
+import pytest
 
 from raytracer_amd.scripts.application import read_exr, read_pfm, write_exr, write_pfm
 
@@ -46,3 +47,45 @@ def test_exr_round_trip_and_layout(tmp_path):
     planes = np.frombuffer(raw, dtype="<f4", count=3 * w, offset=offs[2] + 8).reshape(3, w)
     assert np.array_equal(planes[0].view(np.uint32), img[2, :, 2].view(np.uint32))     # B plane first
     assert np.array_equal(planes[2].view(np.uint32), img[2, :, 0].view(np.uint32))     # R plane last
+
+
+def test_tone_map_and_gamma_hooks():
+    """application.py:1463-1468 / toScreen.fs.glsl:18-38: x / (x + 1), x ** (1 / gamma)."""
+    from raytracer_amd.scripts.application import gamma_correct, to_display, tone_map
+
+    x = np.array([[[0.0, 1.0, 3.0]]], dtype=np.float32)
+    assert np.array_equal(tone_map(x), np.array([[[0.0, 0.5, 0.75]]], dtype=np.float32))
+    assert np.allclose(gamma_correct(np.array([0.25]), 2.0), [0.5]) and gamma_correct(x).dtype == np.float32
+    d = to_display(np.array([[[0.0, 1.0, 1e9], [-1.0, np.inf, 3.0]]], dtype=np.float32))
+    assert d.dtype == np.uint8 and d[0, 0].tolist() == [0, int(np.float32(0.5) ** np.float32(1 / 2.2) * 255), 255]
+    assert d[0, 1].tolist() == [0, 255, int(np.float32(0.75) ** np.float32(1 / 2.2) * 255)]   # negative -> 0, infinite -> white
+
+
+@pytest.mark.gpu
+def test_files_written_by_the_hip_program_hold_the_oracles_image(hip_lib, oracle_lib, tmp_path):
+    """RayTracerDynamic.save_frame on the HIP path (application.py:1094-1126): the PNG is clip -> x255 -> uint8
+    of the flipped frame, the EXR the flipped float32 frame itself - compared with the ORACLE's render of the
+    same frame and passes, read back from the files."""
+    from PIL import Image
+
+    from conftest import build_suzanne, make_ctx
+    from raytracer_amd.scripts.application import to_display
+    from test_application import _run
+
+    _, prog = _run(hip_lib, tmp_path, frames=1, passes=4, bounces=4)
+    prog.display_png = True
+    prog.save_frame(None, 1, 4)
+    o = make_ctx(oracle_lib, build_suzanne(1), 32, 18)
+    o.render(1, 4, 1, 1, 4, 0)
+    top_down = np.flip(o.read_mean(), axis=0)
+    assert top_down.max() > 0
+    exr = read_exr(prog.target_dir / "f00001_c00004_f4.exr")
+    assert np.array_equal(exr.view(np.uint32), top_down.view(np.uint32))
+    png = np.asarray(Image.open(prog.target_dir / "f00001_c00004_f1.png"))
+    assert np.array_equal(png, (np.clip(top_down, 0.0, 1.0) * 255).astype(np.uint8))
+    assert np.array_equal(np.asarray(Image.open(prog.target_dir / "f00001_c00004_tm.png")), to_display(top_down))
+    assert np.array_equal(read_pfm(prog.target_dir / "f00001_c00004_f4.pfm").view(np.uint32), o.read_mean().view(np.uint32))
+    # earlier cycles were dumped at the reference's cadence (1..9, then every 10th): cycle 2 = the running mean after 2 passes
+    o.reset_accum()
+    o.render(1, 2, 1, 1, 4, 0)
+    assert np.array_equal(read_exr(prog.target_dir / "f00001_c00002_f4.exr").view(np.uint32), np.flip(o.read_mean(), axis=0).view(np.uint32))
