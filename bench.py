@@ -83,9 +83,13 @@ def main() -> None:
     ap.add_argument("--reference-structure", action="store_true", help="traverse the reference's own BVH instead of the SAH one")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the untimed legs on the reference's own BVH (profiling runs)")
     args = ap.parse_args()
+    if os.environ.get("RT_BENCH_WATCHDOG"):            # seconds: dump every thread's stack and exit if the run is still going then
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
     wl = dict(WORKLOADS[args.workload])
     if REHEARSAL:
-        wl.update(width=320, height=180, passes=4)
+        wl.update(width=160, height=90, passes=4)
     WIDTH, HEIGHT, PASSES, RPP, BOUNCES = wl["width"], wl["height"], wl["passes"], wl["rpp"], wl["bounces"]
     if args.steps is None:
         args.steps = wl["steps"]
@@ -156,10 +160,22 @@ def main() -> None:
         first_pass, n_passes, stride = shard_passes(PASSES, rank, world)
         total_passes = PASSES
 
-    def step():
+    def render():
         ctx.reset_accum()
         if n_passes:
             ctx.render(first_pass, n_passes, stride, RPP, BOUNCES, ffi.RT_ACCUM_SUM if sum_mode else ffi.RT_ACCUM_MEAN)
+
+    def step():
+        if REHEARSAL and world > 1:
+            # ranks that SHARE one GPU take turns: two persistent kernels preempting each other can take minutes
+            # (context save/restore of a full chip per time slice); the code path is the same
+            for r in range(world):
+                if r == rank:
+                    render()
+                    torch.cuda.synchronize(dev)
+                dist.barrier()
+        else:
+            render()
         if sum_mode:
             dist.all_reduce(accum)         # RCCL over xGMI; same stream as the render
             ctx.set_accum_passes(total_passes)
@@ -308,7 +324,7 @@ def main() -> None:
             "reference_structure": other,
         }
         if REHEARSAL:
-            out["rehearsal"] = "RT_BENCH_REHEARSAL=1: 320x180, 4 passes - not a measurement"
+            out["rehearsal"] = "RT_BENCH_REHEARSAL=1: 160x90, 4 passes - not a measurement"
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

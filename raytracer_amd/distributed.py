@@ -191,9 +191,15 @@ def main(argv=None) -> None:
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RT_BENCH_BACKEND=gloo: rehearsal of the N > 1 code path with several ranks sharing one GPU (nccl = RCCL needs a GPU per rank)
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     sc = S.build()
 
     def override(cam, i):
