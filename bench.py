@@ -6,8 +6,8 @@ Default workload = BASELINE.json configs[1]: Suzanne room, 1920x1080, 64 spp as 
 991 316 triangles, 3840x2160, 256 passes), `--workload dragon` = configs[4] (the 192-mesh dragon
 scene, 1080p, 64 passes, 8 bounces); the driver's line stays on the default.
 
-A "step" = one full render of that frame (persistent k_trace launches over all passes plus the
-k_accumulate launches that fold them; scene and accumulator resident in HBM).  ray = one
+A "step" = one full render of that frame (one persistent k_trace launch over all passes, which
+also folds them into the accumulator; scene and accumulator resident in HBM).  ray = one
 closest-hit query (calculateRayCollision, shaders/raytracer.fs.glsl:518-641 of the reference),
 counted exactly in-kernel by a separate counting launch of the same deterministic work.
 
@@ -216,13 +216,15 @@ def main() -> None:
     info = ctx.info()
     launches = max(int(st["launches"]), 1)
     kern_ms = st["kernel_ms"] / launches
-    per_step = max(1, launches // max(args.steps, 1))            # k_trace launches one step needs (2^27 samples each at most)
+    per_step = max(1, launches // max(args.steps, 1))            # k_trace launches one step needs (1024 passes each at most)
     # per-launch algorithmic work of THIS rank (rank 0 reports its own kernel)
     flop_launch = (FLOP_BOX * counts["box_tests"] + FLOP_TRI * counts["tri_tests"] + FLOP_HIT * counts["shaded_hits"]) / per_step
     # bytes the traversal touches, as if every fetch went to memory ...
     byte_launch = (BYTE_BOX * counts["box_tests"] + BYTE_TRI * counts["tri_tests"] + BYTE_HIT * counts["shaded_hits"]) / per_step
-    # ... and the only stream that has to reach HBM: one float3 per (pixel, pass), folded by k_accumulate
-    hbm_launch = 12.0 * WIDTH * HEIGHT * n_passes / per_step
+    # ... and the only data that has to reach HBM: the accumulator, read and written once per pixel per launch
+    # (the radiance of the samples in flight is staged per wave, 12 KB each, and folded by the wave itself)
+    hbm_launch = 24.0 * WIDTH * HEIGHT
+    stage_launch = 24.0 * WIDTH * HEIGHT * n_passes / per_step
     achieved_tflops = flop_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
     achieved_gbs = hbm_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     cache_gbs = byte_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -315,7 +317,9 @@ def main() -> None:
                         "frac": round(achieved_gbs / PEAK_HBM_GBS, 4),
                         "measured_frac": None if hbm_frac is None else round(hbm_frac, 4),
                         "algorithmic_bytes_per_launch": int(hbm_launch),
-                        "note": "the per-(pixel, pass) radiance stream, 12 B per sample: the only data that must reach HBM; "
+                        "staging_bytes_per_launch": int(stage_launch),
+                        "note": "algorithmic = the accumulator, 12 B read + 12 B written per pixel per launch; staging = 12 B written + 12 B "
+                                "read per sample in the waves' staging slots (75 MB in all, cache resident in principle); "
                                 "measured_frac = roofline.traffic / launch time / peak; not the bound of this kernel"},
                 "cache": {"node_triangle_bytes_per_launch": int(byte_launch), "rate_GBps": round(cache_gbs, 1),
                           "note": "32 B/box test + 36 B/triangle test + 48 B/hit (SURVEY.md 8d), served by L1/L2 (Infinity Cache for subdiv4k)"},

@@ -170,17 +170,18 @@ int rt_render(rt_ctx* ctx, uint32_t first_pass, uint32_t n_passes, uint32_t pass
 /* NO counterpart in the reference.  For callers that cannot allocate device memory while they
  * call - code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc:
  * rt_render with every scratch buffer of its launches (the work counter, the node stack entries
- * beyond the LDS ones, the per-(pass, pixel) radiance of the launch in flight) in one file-scope
- * device array of RT_STATIC_SCRATCH_BYTES instead of hipMalloc'ed memory.  Same arguments, same
- * image bit for bit; calls no hipMalloc/hipFree, creates no events (kernel_ms of rt_get_stats does
- * not grow).  Limits: one pass of the image must fit the radiance part of the scratch:
- * width*height <= 4 194 282 pixels (1920x1080 fits, 3840x2160 does not: RT_E_LIMIT); more passes
- * than fit are split into several launches inside the call; a scene whose node stack exceeds LDS
- * keeps its deep entries in 16 MiB of the scratch and runs on fewer workgroups if they do not
- * all fit.  Every context on a GPU shares that GPU's array, which keeps the last call's
- * contents: calls that overlap on one GPU (two contexts, two streams)
- * race; calls in stream order on one context do not.  Scene, camera, image size and accumulator
- * must have been set up before (those calls allocate). */
+ * beyond the LDS ones, the waves' staging slots for the radiance of the samples in flight) in one
+ * file-scope device array of RT_STATIC_SCRATCH_BYTES instead of hipMalloc'ed memory.  Same
+ * arguments, same image bit for bit; calls no hipMalloc/hipFree, creates no events (kernel_ms of
+ * rt_get_stats does not grow).  Limits: the array holds the staging slots of 8192 waves at 256
+ * samples per job, which is more than a launch uses, so any image size rt_resize accepts and any
+ * number of passes go through (more than 1024 passes are split into launches inside the call); a
+ * launch whose scratch would not fit - only a BVH whose node stack exceeds LDS by far, or more than
+ * 256 passes per launch, which need larger staging slots - runs on fewer workgroups, and
+ * is refused with RT_E_LIMIT if not even one workgroup fits.  Every context on a GPU shares that
+ * GPU's array, which keeps the last call's contents: calls that overlap on one GPU (two contexts,
+ * two streams) race; calls in stream order on one context do not.  Scene, camera, image size and
+ * accumulator must have been set up before (those calls allocate). */
 #define RT_STATIC_SCRATCH_BYTES (64u << 20)
 int rt_render_static(rt_ctx* ctx, uint32_t first_pass, uint32_t n_passes, uint32_t pass_stride,
                      int rays_per_pixel, int max_bounces, int flags);

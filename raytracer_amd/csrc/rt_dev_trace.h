@@ -30,11 +30,19 @@
 //   tri_box  RT_ACCEL_SAH scenes: 2 x float4 per slot, the box of the triangle's leaf in the
 //            REFERENCE's tree (what decides whether a hit found through the SAH tree counts).
 //   mats     the 80-byte std140 Material of every mesh, as uploaded.
-//   totals   one float3 per (pass, pixel) of the launch: k_trace writes, k_accumulate folds.
+//   stage    per wave: two slots of one float3 per sample of a JOB (see below); the wave that traced a
+//            job folds it into the accumulator itself, passes in order.
 //
-// Execution model: persistent waves take chunks of 256 samples (one pass over a
-// 16x16 pixel block) from a launch-wide counter; every lane runs one sample at a time and takes
-// the next one of its wave's chunk when it is done.  A lane holds node work (record in hand,
+// Execution model: persistent waves take JOBS from a launch-wide counter.  A job is a
+// small tile of pixels (tile_w x tile_h, powers of two) with ALL passes of the launch, ~512 samples;
+// every lane runs one sample at a time and takes the next one of its wave's job when it is done
+// (pass-major inside the job, so the 64 lanes of a wave trace a handful of pixels over several
+// passes at once).  The radiance of each sample is parked in the wave's staging slot of the job;
+// when the last sample of a job has finished, the wave applies the running mean (or the sum) to the
+// job's pixels pass by pass, in order, with the reference's expressions (:1008-1021) - the only
+// place the accumulator is touched: 12 bytes read and 12 written per pixel per launch.  A wave
+// holds two jobs at most: the one it is handing out and the previous one whose last samples are
+// still in flight.  A lane holds node work (record in hand,
 // node stack, mesh roots to visit) and leaf work (triangle in progress, 2-entry leaf queue) at
 // once; the wave votes (ballot + popcount) between a node step and a triangle step, runs
 // triangle steps in bursts, and when fewer than `refill_below` lanes still traverse, the lanes
@@ -202,7 +210,9 @@ __device__ __forceinline__ v3 view_point_of(const DevCamera& cam, int px, int py
     return V3(r[0], r[1], r[2]);
 }
 
-enum { M_TRAV = 0, M_PATH = 2, M_DONE = 3 };
+// M_WAIT: the lane needs a sample but both job slots of its wave are still in use (the previous job's last samples
+// are in flight): it asks again at the next path block
+enum { M_TRAV = 0, M_WAIT = 1, M_PATH = 2, M_DONE = 3 };
 
 // deferred leaves a lane can hold (the leaf queue); a lane joins a node step only while two
 // slots are free, because one node step can find two leaves
@@ -228,11 +238,13 @@ struct TraceArgs {
     int32_t* ids;                 // W*H   (first hit)
     float* ts;                    // W*H   (first hit)
     unsigned long long* counters; // 4
-    float* totals;                // n_passes x W*H x 3: per-(pass, pixel) radiance, folded by k_accumulate
-    unsigned int* work_counter;   // next chunk to hand out (zeroed before the launch)
+    float* stage;                 // launch waves x 2 slots x job_cap x 3: radiance of the samples of the jobs in flight
+    unsigned int* work_counter;   // next job to hand out (zeroed before the launch)
     int2* stack_ovf;              // node stack entries beyond the LDS ones: entry e of launch lane g at [(e - stack_depth) * ovf_lanes + g]
     uint32_t ovf_lanes;           // lanes of the launch (grid x 256)
-    uint32_t n_chunks, n_bx, n_by;   // chunks = n_passes x n_by x n_bx blocks of 16x16 pixels
+    uint32_t n_jobs, n_tx, n_ty;  // jobs = n_ty x n_tx tiles of (1 << tile_lx) x (1 << tile_ly) pixels, each with all n_passes passes
+    uint32_t tile_lx, tile_ly;
+    uint32_t job_cap;             // samples a staging slot holds (>= pixels of a tile x n_passes)
     uint32_t first_pass, n_passes, pass_stride;
     int rays_per_pixel, max_bounces, sum_mode;
     int recheck_all;              // SAH, tests only: repeat every query that hit a triangle with the per-hit check on
@@ -244,7 +256,11 @@ struct TraceArgs {
 // Everything only the path block reads (camera, atmosphere, sampling parameters, output and
 // material pointers) is read from an LDS copy of the kernel arguments there: held in scalar
 // registers across the traversal loop it costs ~70 SGPRs and spills.
-struct PathConsts { TraceArgs a; };
+// Per-wave bookkeeping of the two jobs a wave can hold (a lane's `elem` says which slot its sample is in): tile origin, samples that
+// must finish before the job can be folded (0 = slot free), samples finished so far.  Wave-private LDS, 16 bytes:
+// the Suzanne room on the reference's BVH fills the LDS of six workgroups per CU to within 80 bytes.
+struct WaveJobs { uint16_t ox[2], oy[2], expected[2], done[2]; };
+struct PathConsts { TraceArgs a; WaveJobs wj[RT_BLOCK / 64]; };
 #define RT_PC_F4 ((int)((sizeof(PathConsts) + 15) / 16))   // float4 slots of LDS it takes
 
 // material index encoding: -1 atmosphere (kernel argument), [0,256) mesh, 256+i sphere i
@@ -328,6 +344,98 @@ __device__ __forceinline__ bool ref_leaf_box_passes(const DevScene& S, int slot,
     return box_test(org, inv, rb[0], rb[1], ta, tb);
 }
 
+// Device memory reached through a pointer that was read back from the LDS copy of the kernel arguments: say so where
+// it is free (fold_job), so that the compiler emits global_load/global_store instead of flat ones.  (In the path block
+// itself the same qualification was measured at +4 % - the scheduler then orders that block's loads worse - and is not used.)
+#define RT_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ RT_GLOBAL T* as_global(T* p) { return (RT_GLOBAL T*)p; }
+
+// pixel coordinates of a lane's sample: x in the low half, y in the high half (images are <= 32768 a side)
+__device__ __forceinline__ int px_of(uint32_t pxy) { return (int)(pxy & 0xffffu); }
+__device__ __forceinline__ int py_of(uint32_t pxy) { return (int)(pxy >> 16); }
+
+// Every sample of the job in `slot` has finished: fold its radiance into the accumulator, for each pixel the passes
+// of the launch in order, with the reference's expressions (raytracer.fs.glsl:1008-1021: divide by RAYS_PER_PIXEL,
+// running mean with weight 1/pass; RT_ACCUM_SUM adds instead).  Wave-uniform call; a lane takes one (pixel, channel)
+// of the tile.  The weight of pass p is the same for every lane, so lane j computes the one of pass pb + j once per
+// 64 passes and the loop reads it with v_readlane.  RT_FOLD_BATCH passes per trip: their loads are issued together and
+// unconditionally (a lane without an item reads element 0, a pass beyond the last re-reads the last), then the
+// recurrence runs over them in order.  (Inlined: as a called function it cost the caller one spilled register.)
+__device__ __forceinline__ float* stage_of_wave(const TraceArgs& P, int wave) {
+    return P.stage + (size_t)(blockIdx.x * (RT_BLOCK / 64) + wave) * 2 * P.job_cap * 3;
+}
+
+#ifndef RT_FOLD_BATCH
+#define RT_FOLD_BATCH 4   // passes whose loads are in flight together (8 costs the path block a spilled register)
+#endif
+template <bool ONE_RAY, bool SUM>
+__device__ __forceinline__ float fold_passes(float col, const RT_GLOBAL float* st, uint32_t idx, uint32_t stride, uint32_t n_passes, uint32_t first,
+                                             uint32_t pass_stride, float rpp, int lane) {
+    // st is wave-uniform, idx the lane's element of pass 0: st[idx + pass * stride] = one 32-bit add and one load per pass
+    for (uint32_t pb = 0; pb < n_passes; pb += 64) {
+        const float wl = 1.0f / (float)(first + (pb + (uint32_t)lane) * pass_stride);      // :1015, pass pb + lane
+        const uint32_t pe = min(64u, n_passes - pb);
+        for (uint32_t j0 = 0; j0 < pe; j0 += RT_FOLD_BATCH) {
+            float tv[RT_FOLD_BATCH];
+            const uint32_t o0 = (pb + j0) * stride;
+            if (j0 + RT_FOLD_BATCH <= pe) {
+#pragma unroll
+                for (uint32_t u = 0; u < RT_FOLD_BATCH; u++) tv[u] = st[idx + (o0 + u * stride)];
+            } else {
+#pragma unroll
+                for (uint32_t u = 0; u < RT_FOLD_BATCH; u++) tv[u] = st[idx + (pb + min(j0 + u, pe - 1)) * stride];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < RT_FOLD_BATCH; u++) {
+                if (j0 + u < pe) {                                                        // wave-uniform
+                    const float total = ONE_RAY ? tv[u] : tv[u] / rpp;                   // :1009 (x / 1 is x)
+                    if (SUM) col = col + total;
+                    else {
+                        const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), (int)(j0 + u))), om = 1.0f - w;
+                        col = col * om + total * w;                                      // :1016-1021
+                    }
+                }
+            }
+        }
+    }
+    return col;
+}
+
+__device__ __forceinline__ void fold_job(const TraceArgs* Pp, const WaveJobs* wj, int slot, float* stage_wave) {
+#ifdef RT_NO_FOLD   // timing experiment only: what the fold itself costs
+    return;
+#endif
+#ifdef RT_FOLD_NEVER   // timing experiment only: the fold's code is there (registers, scheduling) but never runs
+    if (Pp->max_bounces != 12345) return;
+#endif
+    const TraceArgs& P = *Pp;
+    const int lane = threadIdx.x & 63;
+    const int tw = 1 << P.tile_lx, npx = tw << P.tile_ly;
+    const int ox = wj->ox[slot], oy = wj->oy[slot];
+    const int W = P.cam.width, H = P.cam.height;
+    const uint32_t n_passes = P.n_passes, first = P.first_pass, pstride = P.pass_stride;
+    const bool one_ray = P.rays_per_pixel == 1, sum_mode = P.sum_mode != 0;
+    const float rpp = (float)P.rays_per_pixel;
+    RT_GLOBAL float* accum = as_global(P.accum);
+    const RT_GLOBAL float* st = as_global(stage_wave) + (size_t)slot * P.job_cap * 3;
+    for (int base = 0; base < 3 * npx; base += 64) {
+        const int item = base + lane;
+        const int lp = item / 3, ch = item - 3 * lp;
+        const int x = ox + (lp & (tw - 1)), y = oy + (lp >> P.tile_lx);
+        const bool live = item < 3 * npx && x < W && y < H;
+        RT_GLOBAL float* acc = accum + ((size_t)(live ? y : 0) * W + (live ? x : 0)) * 3 + ch;
+        float col = live ? *acc : 0.0f;
+        const uint32_t idx = live ? (uint32_t)item : 0u;
+        const uint32_t stride = (uint32_t)npx * 3u;                                      // floats between the passes of one item
+        if (sum_mode) col = one_ray ? fold_passes<true, true>(col, st, idx, stride, n_passes, first, pstride, rpp, lane)
+                                    : fold_passes<false, true>(col, st, idx, stride, n_passes, first, pstride, rpp, lane);
+        else col = one_ray ? fold_passes<true, false>(col, st, idx, stride, n_passes, first, pstride, rpp, lane)
+                           : fold_passes<false, false>(col, st, idx, stride, n_passes, first, pstride, rpp, lane);
+        if (live) *acc = col;
+    }
+}
+
 template <bool STATS, bool CULL, bool FIRST_HIT, bool SAH, bool DEEP>
 __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) {
     const DevScene& S = a.scene;
@@ -359,20 +467,23 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     SchedStats sch = {0, 0, 0, 0, 0, 0};
 
     // ---- wave-uniform work cursor ---------------------------------------------------------
-    // Work is handed out in chunks of 256 samples = one pass over one 16x16 pixel block, taken
-    // from a launch-wide counter by whichever wave runs dry; a lane whose sample is finished
-    // takes the next one of its wave's chunk, so no lane waits for a slower neighbour and the
-    // launch ends within one chunk's time on every SIMD.
-    uint32_t w_off = 256u;     // next sample of the wave's chunk (256 = used up)
-    uint32_t w_pass = 0;
-    int w_x0 = 0, w_y0 = 0;
+    // Work is handed out in jobs = one small tile of pixels with all passes of the launch (~512 samples),
+    // taken from a launch-wide counter by whichever wave runs dry; a lane whose sample is finished
+    // takes the next one of its wave's job (pass-major), so no lane waits for a slower neighbour and
+    // the launch ends within one job's time on every SIMD.
+    const int wave = threadIdx.x >> 6;
+    WaveJobs* wj = &s_pc->wj[wave];
+    if (lane == 0) { wj->done[0] = wj->done[1] = 0; wj->expected[0] = wj->expected[1] = 0; }
+    // (job shape and staging base are read from the LDS argument copy where the path block needs them: scalar
+    // registers are as scarce in this kernel as vector ones)
+    uint32_t w_left = 0;       // samples of the wave's job not handed out yet
+    int w_x0 = 0, w_y0 = 0, w_slot = 0;
     bool w_dry = false;        // the launch's counter is exhausted
-    const size_t n_px = (size_t)cam.width * cam.height;
 
     // ---- per-lane state -----------------------------------------------------------------
     int mode = M_PATH;
-    bool have = false;         // holds a sample (pixel pxy of pass pass_no)
-    uint32_t pxy = 0, pass_no = 0;
+    bool have = false;         // holds a sample: pixel pxy, staging element `elem` of its wave (slot * job_cap + pass * tile pixels + pixel of the tile)
+    uint32_t pxy = 0, elem = 0;
     int s = 0;                 // paths of the current sample started
     uint32_t rng = 0;
     bool fresh = true;         // no path in flight: the path block generates a camera sample
@@ -553,11 +664,11 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 } while (cTn > 0 && 8 * cTn >= a.burst8 * lim);
             }
         }
-        if (__ballot(mode == M_PATH) == 0) break;                  // every lane is M_DONE
+        if (__ballot(mode == M_PATH) == 0) break;                  // every lane is M_DONE (a lane in M_WAIT implies samples in flight, i.e. lanes that traverse)
 
         // =============== path phase: shade the finished query, start the next one ===============
         if (STATS) { sch.path_steps++; sch.path_lanes += __popcll(__ballot(mode == M_PATH)); }
-        bool need = false, start = false, redo = false;
+        bool need = mode == M_WAIT, start = false, redo = false, completed = false;
         if (mode == M_PATH) {
             if (!fresh) {
                 if (FIRST_HIT) {
@@ -572,7 +683,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     }
                     if (redo) start = true;
                     else {
-                        const size_t pix = (size_t)(pxy >> 16) * cam.width + (pxy & 0xffffu);
+                        const size_t pix = (size_t)py_of(pxy) * cam.width + px_of(pxy);
                         P.ids[pix] = id;
                         P.ts[pix] = tv.best_t;
                         have = false;
@@ -687,49 +798,89 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     else { bounce += !redo; start = true; }
                 }
                 if (fresh && !FIRST_HIT) {                         // the path is over (:989): totalIncomingLight += inc
-                    // the sample's running sum lives in the radiance buffer (three fewer live registers);
-                    // k_accumulate divides by RAYS_PER_PIXEL (:1009)
-                    float* o = P.totals + ((size_t)pass_no * n_px + (size_t)(pxy >> 16) * cam.width + (pxy & 0xffffu)) * 3;
+                    // the sample's running sum lives in the staging slot of its job (three fewer live registers):
+                    // element (pass, pixel of the tile); fold_job divides by RAYS_PER_PIXEL (:1009)
+                    float* o = stage_of_wave(P, wave) + (size_t)elem * 3;
                     const v3 sum = s == 1 ? V3(0.f, 0.f, 0.f) : V3(o[0], o[1], o[2]);
                     o[0] = sum.x + inc.x; o[1] = sum.y + inc.y; o[2] = sum.z + inc.z;
-                    if (s == P.rays_per_pixel) { s = 0; have = false; }   // the sample is complete (:1008-1010)
+                    if (s == P.rays_per_pixel) { s = 0; have = false; completed = true; }   // the sample is complete (:1008-1010)
                 }
             }
             need = fresh && !have;
         }
+        if (!FIRST_HIT) {                                          // samples finished in this block, per job slot (wave-uniform)
+            const uint64_t c0 = __ballot(completed && elem < P.job_cap), c1 = __ballot(completed && elem >= P.job_cap);
+            if (lane == 0) {
+                if (c0) wj->done[0] = (uint16_t)(wj->done[0] + __popcll(c0));
+                if (c1) wj->done[1] = (uint16_t)(wj->done[1] + __popcll(c1));
+            }
+        }
         // ---- hand out samples: wave-uniform code, reached by every lane of the wave ----
         for (uint64_t nm = __ballot(need); nm != 0; nm = __ballot(need)) {
-            if (w_off == 256u) {
+            if (w_left == 0) {                                     // the job in hand is handed out completely
+                int free_slot = 0;
+                if (!FIRST_HIT) {
+                    // a job whose samples have all finished is folded into the accumulator and its slot given back
+                    free_slot = -1;
+#pragma unroll
+                    for (int k = 1; k >= 0; k--) {
+                        const uint32_t expc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wj->expected[k]);
+                        if (expc && (uint32_t)__builtin_amdgcn_readfirstlane((int)wj->done[k]) == expc) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the staged radiance was written by other lanes of this wave
+                            fold_job(&P, wj, k, stage_of_wave(P, wave));
+                            if (lane == 0) wj->expected[k] = 0;
+                            free_slot = k;
+                        } else if (!expc) free_slot = k;
+                    }
+                }
                 if (w_dry) { if (need) mode = M_DONE; break; }
+                if (free_slot < 0) { if (need) mode = M_WAIT; break; }   // both jobs still have samples in flight: ask again later
                 unsigned int c = 0;
                 if (lane == 0) c = atomicAdd(P.work_counter, 1u);
                 c = __builtin_amdgcn_readfirstlane(c);
-                if (c >= (unsigned int)__builtin_amdgcn_readfirstlane((int)P.n_chunks)) { w_dry = true; continue; }
-                const uint32_t n_bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.n_bx);
-                const uint32_t per_pass = n_bx * (uint32_t)__builtin_amdgcn_readfirstlane((int)P.n_by);
-                w_pass = c / per_pass;
-                const uint32_t r = c - w_pass * per_pass, by = r / n_bx;
-                w_x0 = (int)((r - by * n_bx) * 16u);
-                w_y0 = (int)(by * 16u);
-                w_off = 0;
+                if (c >= (unsigned int)__builtin_amdgcn_readfirstlane((int)P.n_jobs)) { w_dry = true; continue; }
+                const uint32_t n_tx = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.n_tx);
+                const uint32_t tile_lx = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.tile_lx), tile_ly = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.tile_ly);
+                const uint32_t ty = c / n_tx;
+                w_x0 = (int)((c - ty * n_tx) << tile_lx);
+                w_y0 = (int)(ty << tile_ly);
+                w_slot = free_slot;
+                w_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.n_passes) << (tile_lx + tile_ly);
+                if (!FIRST_HIT && lane == 0) {
+                    // samples that will be traced: the tile's pixels inside the image x all passes
+                    const uint32_t cw = (uint32_t)min(1 << tile_lx, cam.width - w_x0), chh = (uint32_t)min(1 << tile_ly, cam.height - w_y0);
+                    wj->ox[free_slot] = (uint16_t)w_x0;
+                    wj->oy[free_slot] = (uint16_t)w_y0;
+                    wj->expected[free_slot] = (uint16_t)(cw * chh * P.n_passes);     // <= 1024 (RT_MAX_LAUNCH_PASSES, job shape)
+                    wj->done[free_slot] = 0;
+                }
             }
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nm, 0u));
-            const uint32_t avail = 256u - w_off;
+            const uint32_t avail = w_left;
             if (need && rank < avail) {
-                const uint32_t o = w_off + rank;                   // 4 tiles of 8x8 pixels
-                const int x = w_x0 + (int)(((o >> 6) & 1u) * 8u + (o & 7u));
-                const int y = w_y0 + (int)((o >> 7) * 8u + ((o >> 3) & 7u));
+                const uint32_t tile_lx = P.tile_lx, job_px_log = tile_lx + P.tile_ly;
+                const uint32_t o = (P.n_passes << job_px_log) - w_left + rank;   // pass-major: (pass, pixel of the tile)
+                const uint32_t lp = o & ((1u << job_px_log) - 1u);
+                const int x = w_x0 + (int)(lp & ((1u << tile_lx) - 1u));
+                const int y = w_y0 + (int)(lp >> tile_lx);
                 need = false;                                      // consumed, inside the image or not
-                if (x < cam.width && y < cam.height) { have = true; pxy = (uint32_t)x | ((uint32_t)y << 16); pass_no = w_pass; }
+                if (x < cam.width && y < cam.height) {
+                    have = true;
+                    pxy = (uint32_t)x | ((uint32_t)y << 16);
+                    elem = o + (w_slot ? P.job_cap : 0u);
+                    // per-pass seed of the pixel (:956-957); the state runs on across the RAYS_PER_PIXEL samples
+                    rng = (uint32_t)y * (uint32_t)cam.width + (uint32_t)x + (P.first_pass + (o >> job_px_log) * P.pass_stride) * 747796405u;
+                    mode = M_PATH;                                 // (a lane that was waiting for a job slot)
+                }
             }
-            w_off += min((uint32_t)__popcll(nm), avail);
+            w_left -= min((uint32_t)__popcll(nm), avail);
         }
+        // a lane that consumed a sample outside the image, or none at all, has nothing to start in this block
+        if (mode == M_WAIT && have) mode = M_PATH;
         if (mode == M_PATH) {
             if (fresh && have) {
                 {
-                    const uint32_t pix = (pxy >> 16) * (uint32_t)cam.width + (pxy & 0xffffu);
-                    if (s == 0) rng = pix + (P.first_pass + pass_no * P.pass_stride) * 747796405u;   // :956-957
-                    const v3 view_point = view_point_of(cam, (int)(pxy & 0xffffu), (int)(pxy >> 16));
+                    const v3 view_point = view_point_of(cam, px_of(pxy), py_of(pxy));
                     // camera sample (:972-987); four draws: DoF x,y then AA x,y
                     const float r1 = random_value(rng), r2 = random_value(rng), r3 = random_value(rng), r4 = random_value(rng);
                     const float nearp = cam.view_params[2];
@@ -793,6 +944,19 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     }
                 }
                 mode = M_TRAV;
+            }
+        }
+    }
+    if (!FIRST_HIT) {
+        // every job was folded when its last sample finished (the lane that finishes it asks for the next sample in
+        // the same block); a slot still in use here would be a bookkeeping error: fold what is complete, count the rest
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (__builtin_amdgcn_readfirstlane((int)wj->expected[k])) {
+                if (__builtin_amdgcn_readfirstlane((int)wj->done[k]) == __builtin_amdgcn_readfirstlane((int)wj->expected[k])) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    fold_job(&P, wj, k, stage_of_wave(P, wave));
+                } else if (lane == 0) atomicAdd(a.counters + 15, 1ull);      // rt_get_stats reports it as an internal error
             }
         }
     }

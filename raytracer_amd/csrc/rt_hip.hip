@@ -8,11 +8,11 @@
 //                 bottom-up by tree level (exact: min/max are associative)
 //   k_pack_nodes  copies refreshed child boxes into the 64-byte traversal records
 //   k_tri_flags   refreshes the per-triangle flag word after rt_set_materials
-//   k_trace       ray generation + traversal + bounce loop (shaders/raytracer.fs.glsl main()
-//                 :928-1007 and everything it calls): persistent waves, wave-voted node /
-//                 triangle / path steps (rt_dev_trace.h); writes one radiance value per
-//                 (pass, pixel); FIRST_HIT instantiation = primary-ray closest hit only
-//   k_accumulate  running mean / sum over the passes of a launch (:1008-1042), in pass order
+//   k_trace       ray generation + traversal + bounce loop + accumulation (shaders/raytracer.fs.glsl
+//                 main() :928-1042 and everything it calls): persistent waves, wave-voted node /
+//                 triangle / path steps (rt_dev_trace.h); a wave folds the passes of the pixels
+//                 it traced into the accumulator itself, in pass order; FIRST_HIT instantiation =
+//                 primary-ray closest hit only
 //   k_gather_*    read-back of posed triangles / refit boxes in the reference's std140 order
 // Host: scene upload (traversal-order slots, 64-byte node records, top-level tree for scenes with
 // more than 32 meshes), batched pose/refit, launch logic.  rt_bvh.cpp holds the BVH builder.
@@ -203,31 +203,9 @@ __global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const 
     o[12] = a.x; o[13] = a.y; o[14] = a.z; o[16] = b.x; o[17] = b.y; o[18] = b.z; o[20] = c.x; o[21] = c.y; o[22] = c.z;
 }
 
-// Folds the per-(pass, pixel) radiance of one trace launch into the accumulator, pass by pass in
-// order, with the reference's expressions (raytracer.fs.glsl:1012-1021: running mean with weight
-// 1/pass; RT_ACCUM_SUM adds instead).  Streams n_passes x 12 B per pixel once.
-__global__ __launch_bounds__(256) void k_accumulate(const float* totals, float* accum, size_t n_px, uint32_t first_pass,
-                                                    uint32_t n_passes, uint32_t pass_stride, int rays_per_pixel, int sum_mode) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_px) return;
-    float* acc = accum + i * 3;
-    v3 col = V3(acc[0], acc[1], acc[2]);
-    for (uint32_t p = 0; p < n_passes; p++) {
-        const float* t = totals + ((size_t)p * n_px + i) * 3;
-        const float rpp = (float)rays_per_pixel;
-        const v3 total = V3(t[0] / rpp, t[1] / rpp, t[2] / rpp);     // :1009
-        if (sum_mode) col = col + total;
-        else {
-            const float w = 1.0f / (float)(first_pass + p * pass_stride), om = 1.0f - w;
-            col = V3(col.x * om + total.x * w, col.y * om + total.y * w, col.z * om + total.z * w);
-        }
-    }
-    acc[0] = col.x; acc[1] = col.y; acc[2] = col.z;
-}
-
-// Persistent waves: the grid just fills the chip, and every wave takes 16x16-pixel x 1-pass chunks
-// of samples from a launch-wide counter until none are left (rt_dev_trace.h).  Dynamic LDS: mesh
-// root table + the per-lane node stack / leaf queue columns.
+// Persistent waves: the grid just fills the chip, and every wave takes jobs (a small tile of pixels x
+// all passes of the launch) from a launch-wide counter until none are left (rt_dev_trace.h).  Dynamic
+// LDS: mesh root table + argument copy + the per-lane node stack / leaf queue columns.
 #ifndef RT_WAVES
 #define RT_WAVES 5
 #endif
@@ -238,16 +216,16 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES) void k_trace(TraceArgs a) {
 }
 
 // Scratch of rt_render_static, the entry point that allocates nothing (include/rt_hip.h): the work
-// counter, the node stack entries beyond the LDS ones and the per-(pass, pixel) radiance of one
-// launch live in this file-scope array instead of hipMalloc'ed buffers.  Every GPU the library
+// counter, the node stack entries beyond the LDS ones and the waves' staging slots (radiance of the
+// samples of the jobs in flight) live in this file-scope array instead of hipMalloc'ed buffers.  Every GPU the library
 // runs on holds its own copy until the process ends; its DEVICE address is taken once per context
 // with hipGetSymbolAddress (rt_create) - in host code the name `scratch` is only a stand-in.
 //   [0, 256)                                 work counter
 //   [256, 256 + RT_STATIC_OVF_BYTES)         stack_ovf (int2 per deep entry and launch lane)
-//   [256 + RT_STATIC_OVF_BYTES, end)         totals (float3 per (pass, pixel) of the launch in flight)
+//   [256 + RT_STATIC_OVF_BYTES, end)         stage (per wave: 2 slots x job_cap float3)
 #define RT_STATIC_OVF_BYTES ((size_t)16 << 20)
-#define RT_STATIC_TOTALS_OFF ((size_t)256 + RT_STATIC_OVF_BYTES)
-static_assert(RT_STATIC_SCRATCH_BYTES > RT_STATIC_TOTALS_OFF + (1u << 20), "scratch layout");
+#define RT_STATIC_STAGE_OFF ((size_t)256 + RT_STATIC_OVF_BYTES)
+static_assert(RT_STATIC_SCRATCH_BYTES > RT_STATIC_STAGE_OFF + (1u << 20), "scratch layout");
 static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 
 // ----------------------------------------------------------------------------------------
@@ -388,6 +366,10 @@ void level_lists(const std::vector<int>& vdepth, int max_depth, std::vector<int>
     for (size_t v = 0; v < vdepth.size(); v++) level_nodes[fill[vdepth[v]]++] = (int)v;
 }
 
+#define RT_JOB_SAMPLES 512u          // samples of a job: tail of a launch ~ half a job per wave, fold at (tile pixels x 3) lanes
+#define RT_JOB_SAMPLES_STATIC 256u   // rt_render_static: 6144 waves x 2 slots x 256 x 12 B fit its 48 MiB
+#define RT_MAX_LAUNCH_PASSES 1024u   // a job holds all passes of its launch
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // stream in use
@@ -406,7 +388,7 @@ struct rt_ctx {
     DevBuf<SphereDev> spheres;
     DevBuf<unsigned long long> counters;
     DevBuf<unsigned int> work_counter;
-    DevBuf<float> totals;                 // per-(pass, pixel) radiance of one trace launch (grow-only)
+    DevBuf<float> stage;                  // staging slots of the launch's waves: 2 x job_cap float3 each (grow-only)
     int n_cus = 0;
     size_t lds_per_cu = 160 * 1024;
     int stack_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // per k_trace variant: node stack entries in LDS for the scene in place
@@ -448,6 +430,7 @@ struct rt_ctx {
     bool cull = false;                    // conservative distance culling (rt_set_cull)
     int node_bias = 0;
     int burst8 = -1;                      // RT_BURST8; -1 = measured default (4 of 8 lanes, SAH scenes: 3 of 8)
+    uint32_t job_samples = RT_JOB_SAMPLES;   // RT_JOB_SAMPLES: samples of a job (measurements)
     int recheck_all = 0;                  // RT_SAH_RECHECK_ALL: run the SAH structure's repeat path on every query (tests)
     int refill_below = 0;                 // lanes still traversing below which a wave shades/refills; 0 = measured default
     // camera / image
@@ -609,6 +592,18 @@ DevScene scene_view(const rt_ctx* c) {
     return s;
 }
 
+// A job = a tile of (1 << lx) x (1 << ly) pixels with all `n_passes` passes of the launch: the largest power-of-two
+// tile that keeps the job at `target` samples or fewer (one pixel if the passes alone exceed it), as square as possible.
+void set_job_shape(const rt_ctx* c, TraceArgs& a, uint32_t n_passes, uint32_t target) {
+    uint32_t l = 0;
+    while (l < 10 && ((uint64_t)2 << l) * n_passes <= target) l++;
+    a.tile_lx = (l + 1) / 2;
+    a.tile_ly = l / 2;
+    a.n_tx = ((uint32_t)c->cam.width + (1u << a.tile_lx) - 1) >> a.tile_lx;
+    a.n_ty = ((uint32_t)c->cam.height + (1u << a.tile_ly) - 1) >> a.tile_ly;
+    a.n_jobs = a.n_tx * a.n_ty;
+    a.job_cap = n_passes << l;
+}
 void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.scene = scene_view(c);
     a.cam = c->cam;
@@ -617,11 +612,11 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.ids = nullptr;
     a.ts = nullptr;
     a.counters = c->counters.p;
-    a.totals = c->totals.p;
+    a.stage = nullptr;
     a.work_counter = c->work_counter.p;
-    a.n_bx = (uint32_t)(c->cam.width + 15) / 16;
-    a.n_by = (uint32_t)(c->cam.height + 15) / 16;
-    a.n_chunks = 0;
+    a.n_tx = a.n_ty = a.n_jobs = 0;           // set_job_shape
+    a.tile_lx = a.tile_ly = 0;
+    a.job_cap = 0;
     a.node_bias = c->node_bias;
     a.burst8 = c->burst8 >= 0 ? c->burst8 : (c->scene_is_sah ? 3 : 4);
     a.recheck_all = c->recheck_all;
@@ -657,7 +652,7 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     cap = c->stack_lds[key];
     const size_t lds = fixed + (size_t)(cap + RT_LQ_OF(SAH)) * per_ent;
     // every wave takes whole chunks: no point in more waves than chunks
-    unsigned grid = std::max(1u, (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_chunks + 3) / 4));
+    unsigned grid = std::max(1u, (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_jobs + 3) / 4));
     TraceArgs b = a;
     b.scene.stack_depth = cap;
     const size_t deep = (size_t)std::max(0, c->stack_depth - cap);
@@ -667,9 +662,22 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
         const size_t cap_ent = RT_STATIC_OVF_BYTES / sizeof(int2);
         if (deep * RT_BLOCK > cap_ent) return fail(c, RT_E_LIMIT, "rt_render_static: BVH too deep for the static scratch (%zu entries per lane beyond LDS)", deep);
         if (deep) grid = (unsigned)std::min<size_t>(grid, cap_ent / (deep * RT_BLOCK));
+        // ... and the staging slots of its waves: 2 x job_cap float3 each
+        const size_t per_block = (size_t)(RT_BLOCK / 64) * 2 * a.job_cap * 3 * sizeof(float);
+        if (!FIRST) {
+            if (per_block > RT_STATIC_SCRATCH_BYTES - RT_STATIC_STAGE_OFF) return fail(c, RT_E_LIMIT, "rt_render_static: a job of %u samples does not fit the static scratch", a.job_cap);
+            grid = (unsigned)std::min<size_t>(grid, (RT_STATIC_SCRATCH_BYTES - RT_STATIC_STAGE_OFF) / per_block);
+        }
         b.stack_ovf = (int2*)(c->static_scratch + 256);
         b.work_counter = (unsigned int*)c->static_scratch;
+        b.stage = (float*)(c->static_scratch + RT_STATIC_STAGE_OFF);
     } else {
+        const size_t need_stage = FIRST ? 0 : (size_t)grid * (RT_BLOCK / 64) * 2 * a.job_cap * 3;
+        if (c->stage.n < need_stage) {
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            if (c->stage.alloc(need_stage) != hipSuccess) return fail(c, RT_E_NOMEM, "no device memory for the staging slots of %u workgroups", grid);
+        }
+        b.stage = c->stage.p;
         const size_t need_ovf = deep * (size_t)grid * RT_BLOCK;
         if (c->stack_ovf_n < need_ovf) {
             HIPCK(c, hipStreamSynchronize(c->stream));
@@ -804,6 +812,7 @@ int rt_create(int device, rt_ctx** out) {
     if (const char* e = getenv("RT_BURST8")) c->burst8 = std::max(0, std::min(64, atoi(e)));
     if (const char* e = getenv("RT_SAH_RECHECK_ALL")) c->recheck_all = atoi(e) != 0;
     if (const char* e = getenv("RT_STACK_LDS")) c->stack_lds_force = std::max(0, std::min(64, atoi(e)));
+    if (const char* e = getenv("RT_JOB_SAMPLES")) c->job_samples = (uint32_t)std::max(16, std::min(1024, atoi(e)));
     if (const char* e = getenv("RT_REFILL_BELOW")) c->refill_below = std::max(1, std::min(64, atoi(e)));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -845,7 +854,7 @@ int rt_destroy(rt_ctx* c) {
     for (auto& ev : c->pending_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     free_scene(c);
     c->accum_own.release();
-    c->totals.release();
+    c->stage.release();
     c->work_counter.release();
     c->stack_ovf.release();
     c->counters.release();
@@ -1280,32 +1289,16 @@ static int render_impl(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t st
     a.rays_per_pixel = rpp;
     a.max_bounces = max_bounces;
     a.sum_mode = (flags == RT_ACCUM_SUM);
-    // one launch traces at most ~2^27 camera samples (and at most 2^27 pixel-passes: the
-    // per-(pass, pixel) radiance buffer stays below 1.6 GB); k_accumulate then folds them in order
+    // a job holds all passes of its launch, so a launch takes at most RT_MAX_LAUNCH_PASSES passes; nothing else
+    // bounds it (no per-(pass, pixel) buffer any more): configs[1] and configs[3] are one launch each
     const uint64_t n_px = (uint64_t)c->cam.width * c->cam.height;
     const uint64_t per_pass = n_px * (uint64_t)rpp;
-    uint32_t chunk = (uint32_t)std::max<uint64_t>(1, (1ull << 27) / std::max<uint64_t>(per_pass, 1));
-    if (use_static) {
-        // the radiance of a launch must fit the static scratch: nothing is allocated on this path
-        const uint64_t fit = (RT_STATIC_SCRATCH_BYTES - RT_STATIC_TOTALS_OFF) / (n_px * 12);
-        if (fit < 1)
-            return fail(c, RT_E_LIMIT, "rt_render_static: image of %llu pixels exceeds the %llu pixels one pass may have in the %u MiB static scratch",
-                        (unsigned long long)n_px, (unsigned long long)((RT_STATIC_SCRATCH_BYTES - RT_STATIC_TOTALS_OFF) / 12), (unsigned)(RT_STATIC_SCRATCH_BYTES >> 20));
-        chunk = (uint32_t)std::min<uint64_t>(chunk, fit);
-        a.totals = (float*)(c->static_scratch + RT_STATIC_TOTALS_OFF);
-    } else {
-        const uint32_t most = std::min(chunk, n_passes);
-        if (c->totals.n < (size_t)most * n_px * 3) {
-            HIPCK(c, hipStreamSynchronize(c->stream));
-            if (c->totals.alloc((size_t)most * n_px * 3) != hipSuccess) return fail(c, RT_E_NOMEM, "no device memory for %u passes of radiance", most);
-        }
-        a.totals = c->totals.p;
-    }
+    const uint32_t chunk = RT_MAX_LAUNCH_PASSES;
     c->launch_static = use_static;
     for (uint32_t done = 0; done < n_passes; done += chunk) {
         a.first_pass = first + done * stride;
         a.n_passes = std::min(chunk, n_passes - done);
-        a.n_chunks = a.n_passes * a.n_bx * a.n_by;
+        set_job_shape(c, a, a.n_passes, use_static ? RT_JOB_SAMPLES_STATIC : c->job_samples);
         if (use_static) {                              // no events either: creating one may allocate
             rc = launch_trace(c, a, false);
             if (rc) { c->launch_static = false; return rc; }
@@ -1319,8 +1312,6 @@ static int render_impl(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t st
             t.handed = true;
         }
         c->st.launches++;
-        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, c->stream, a.totals, c->accum,
-                           (size_t)n_px, a.first_pass, a.n_passes, stride, rpp, a.sum_mode);
     }
     c->launch_static = false;
     HIPCK(c, hipGetLastError());
@@ -1369,7 +1360,7 @@ int rt_first_hit(rt_ctx* c, uint32_t pass, int32_t* ids, float* ts) {
     a.rays_per_pixel = 1;
     a.max_bounces = 0;
     a.sum_mode = 0;
-    a.n_chunks = a.n_bx * a.n_by;
+    set_job_shape(c, a, 1, 256);                            // 16 x 16 pixels
     {
         LaunchTimer t;
         HIPCK(c, t.create());
@@ -1462,6 +1453,7 @@ int rt_get_stats(rt_ctx* c, rt_stats_t* o) {
     unsigned long long h[16];
     HIPCK(c, hipMemcpyAsync(h, c->counters.p, 128, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    if (h[15]) return fail(c, RT_E_DEVICE, "internal error: %llu jobs were not folded into the accumulator", h[15]);
     c->st.rays = h[0]; c->st.box_tests = h[1]; c->st.tri_tests = h[2]; c->st.shaded_hits = h[3];
     for (int q = 0; q < 6; q++) c->st.sched[q] = h[4 + q];
     *o = c->st;
