@@ -221,10 +221,11 @@ def main() -> None:
     flop_launch = (FLOP_BOX * counts["box_tests"] + FLOP_TRI * counts["tri_tests"] + FLOP_HIT * counts["shaded_hits"]) / per_step
     # bytes the traversal touches, as if every fetch went to memory ...
     byte_launch = (BYTE_BOX * counts["box_tests"] + BYTE_TRI * counts["tri_tests"] + BYTE_HIT * counts["shaded_hits"]) / per_step
-    # ... and the only data that has to reach HBM: the accumulator, read and written once per pixel per launch
-    # (the radiance of the samples in flight is staged per wave, 12 KB each, and folded by the wave itself)
-    hbm_launch = 24.0 * WIDTH * HEIGHT
+    # ... and the streams that leave the L2: the accumulator, read and written once per pixel per launch, and the radiance of
+    # every sample, written to its wave's staging slot and read back once by the fold (12 + 12 B per (pixel, pass) - SURVEY.md
+    # 8(d)'s figure for passes that are accumulated one by one; the 75 MB of slots do not stay in 8 x 4 MB of L2)
     stage_launch = 24.0 * WIDTH * HEIGHT * n_passes / per_step
+    hbm_launch = 24.0 * WIDTH * HEIGHT + stage_launch
     achieved_tflops = flop_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
     achieved_gbs = hbm_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     cache_gbs = byte_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -318,8 +319,8 @@ def main() -> None:
                         "measured_frac": None if hbm_frac is None else round(hbm_frac, 4),
                         "algorithmic_bytes_per_launch": int(hbm_launch),
                         "staging_bytes_per_launch": int(stage_launch),
-                        "note": "algorithmic = the accumulator, 12 B read + 12 B written per pixel per launch; staging = 12 B written + 12 B "
-                                "read per sample in the waves' staging slots (75 MB in all, cache resident in principle); "
+                        "note": "algorithmic = accumulator (12 B read + 12 B written per pixel per launch) + staging (12 B written + 12 B "
+                                "read per sample in the waves' staging slots, 75 MB in all: they pass through the L2 to the Infinity Cache); "
                                 "measured_frac = roofline.traffic / launch time / peak; not the bound of this kernel"},
                 "cache": {"node_triangle_bytes_per_launch": int(byte_launch), "rate_GBps": round(cache_gbs, 1),
                           "note": "32 B/box test + 36 B/triangle test + 48 B/hit (SURVEY.md 8d), served by L1/L2 (Infinity Cache for subdiv4k)"},

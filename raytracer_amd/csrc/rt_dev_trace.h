@@ -822,7 +822,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 if (!FIRST_HIT) {
                     // a job whose samples have all finished is folded into the accumulator and its slot given back
                     free_slot = -1;
-#pragma unroll
+#pragma nounroll
                     for (int k = 1; k >= 0; k--) {
                         const uint32_t expc = (uint32_t)__builtin_amdgcn_readfirstlane((int)wj->expected[k]);
                         if (expc && (uint32_t)__builtin_amdgcn_readfirstlane((int)wj->done[k]) == expc) {
@@ -949,16 +949,9 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     }
     if (!FIRST_HIT) {
         // every job was folded when its last sample finished (the lane that finishes it asks for the next sample in
-        // the same block); a slot still in use here would be a bookkeeping error: fold what is complete, count the rest
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            if (__builtin_amdgcn_readfirstlane((int)wj->expected[k])) {
-                if (__builtin_amdgcn_readfirstlane((int)wj->done[k]) == __builtin_amdgcn_readfirstlane((int)wj->expected[k])) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    fold_job(&P, wj, k, stage_of_wave(P, wave));
-                } else if (lane == 0) atomicAdd(a.counters + 15, 1ull);      // rt_get_stats reports it as an internal error
-            }
-        }
+        // the same block, which is where finished jobs are folded); a slot still in use here would be a bookkeeping
+        // error: rt_get_stats reports it
+        if (lane == 0 && (wj->expected[0] | wj->expected[1]) != 0) atomicAdd(a.counters + 15, 1ull);
     }
     if (STATS) {
         unsigned long long v[4] = {cnt.rays, cnt.box, cnt.tri, cnt.hits};
