@@ -176,13 +176,15 @@ __device__ __forceinline__ bool sah_widened_hit(float tmin, float tmax, float e2
     return tmin <= fma_(e2 + mo, mi, tmax);
 }
 // a ray with an exactly zero direction component (slab values may be NaN): the reference's
-// ladder on the box widened in space
+// ladder on the box widened in space.  The interval handed to the culling rules is the widened
+// box's too: on an axis with 1/d = inf the unwidened box yields (-inf, -inf) or (+inf, +inf) as
+// soon as the ray passes a rounding error outside it, which the rules would read as "behind the
+// origin" / "beyond the best hit" and drop a box the widened test had just accepted
+// (tests/test_gpu_fuzz.py::test_axis_aligned_rays_and_nan_slabs).  The widened interval contains
+// the unwidened one whenever both are numbers, and NaN never culls.
 __device__ __forceinline__ bool sah_box_test_any(v3 o, v3 inv, float4 lo, float4 hi, float e2, float mo, float& tmin_out, float& tmax_out) {
     const float e = e2 * 0.5f + mo;
-    float ta, tb;
-    const bool h = box_test(o, inv, make_float4(lo.x - e, lo.y - e, lo.z - e, 0.f), make_float4(hi.x + e, hi.y + e, hi.z + e, 0.f), ta, tb);
-    box_test(o, inv, lo, hi, tmin_out, tmax_out);
-    return h;
+    return box_test(o, inv, make_float4(lo.x - e, lo.y - e, lo.z - e, 0.f), make_float4(hi.x + e, hi.y + e, hi.z + e, 0.f), tmin_out, tmax_out);
 }
 
 // Entry distance of a deferred child, kept in 16 bits (LDS is what limits occupancy here): the

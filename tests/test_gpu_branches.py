@@ -83,3 +83,36 @@ def test_deep_stack_entries_in_global_memory(hip_lib, monkeypatch):
             assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
             for k in ("rays", "box_tests", "tri_tests", "shaded_hits"):
                 assert a[3][k] == b[3][k], (sah, cull, n, k)
+
+
+@pytest.mark.gpu
+def test_tiny_jobs_make_lanes_wait_for_a_staging_slot(hip_lib, oracle_lib, monkeypatch):
+    """A wave holds two jobs at most (the one it hands out and the previous one whose last samples are in flight);
+    a lane that needs a sample while both are busy waits (M_WAIT, rt_dev_trace.h).  With the default ~512 samples
+    per job that never happens; RT_JOB_SAMPLES=16 (read at rt_create) makes a job a quarter of a wave-load, so
+    it happens all the time - and folds are four per wave-load.  Same image, bit for bit, as the oracle's; also with
+    2 rays per pixel (a sample's sum is kept in its staging element across its rays), in SUM mode with a stride,
+    with a pass count that is no power of two and with more passes than a weight block (64) holds."""
+    from conftest import build_suzanne, make_ctx
+
+    def run(lib, w, h, first, n, stride, rpp, bounces, flags):
+        c = make_ctx(lib, build_suzanne(0), w, h)
+        if lib.backend == "hip":
+            c.set_cull(True)
+        c.render(first, n, stride, rpp, bounces, flags)
+        img, cnt = c.read_accum()
+        c.close()
+        return img
+
+    cases = [(96, 54, 1, 5, 1, 1, 4, 0), (64, 36, 2, 3, 3, 2, 6, 1), (40, 23, 1, 70, 1, 1, 2, 0), (333, 187, 1, 1, 1, 1, 4, 0)]
+    for case in cases:
+        ref = run(oracle_lib, *case)
+        assert ref.max() > 0
+        for job in ("16", "64", None):
+            if job is None:
+                monkeypatch.delenv("RT_JOB_SAMPLES", raising=False)
+            else:
+                monkeypatch.setenv("RT_JOB_SAMPLES", job)
+            got = run(hip_lib, *case)
+            assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), f"case {case}, RT_JOB_SAMPLES={job}: {(ref != got).any(axis=2).sum()} pixels differ"
+    monkeypatch.delenv("RT_JOB_SAMPLES", raising=False)

@@ -2,7 +2,7 @@
 materials incl. alpha, transmission, mirrors, emitters; 3 - 60 meshes so that both the LDS root
 mask and the top-level tree are taken; random cameras with depth of field) and the
 axis-aligned-ray corner of the slab test: HIP STRICT == oracle bit for bit, HIP CULL == HIP
-STRICT."""
+STRICT; the SAH structure with culling (the bench mode) == oracle on all of them."""
 import numpy as np
 import pytest
 
@@ -70,8 +70,12 @@ def random_scene(seed):
     return sc
 
 
-def _render(lib, sc, w, h, cull, passes, rpp, bounces):
-    c = make_ctx(lib, sc, w, h)
+def _render(lib, sc, w, h, cull, passes, rpp, bounces, sah=False):
+    c = lib.create()
+    c.set_accel(sah)                 # the oracle ignores it
+    c.load_scene(sc)
+    c.load_camera(sc.cam)
+    c.resize(w, h)
     c.set_cull(cull)
     c.enable_stats(True)
     ids, ts = c.first_hit(1)
@@ -97,6 +101,10 @@ def test_random_scenes_bit_exact(oracle_lib, hip_lib, seed):
     ic, tc, c, _ = _render(hip_lib, random_scene(seed), w, h, True, passes, rpp, bounces)
     assert np.array_equal(ig, ic) and np.array_equal(tg.view(np.uint32), tc.view(np.uint32))
     assert np.array_equal(b.view(np.uint32), c.view(np.uint32)), f"seed {seed}: CULL differs from STRICT in {(b != c).any(axis=2).sum()} pixels"
+    # the bench mode (SAH structure + culling) directly against the ORACLE, not against another HIP mode
+    isa, tsa, d, _ = _render(hip_lib, random_scene(seed), w, h, True, passes, rpp, bounces, sah=True)
+    assert np.array_equal(io, isa) and np.array_equal(to.view(np.uint32), tsa.view(np.uint32)), f"seed {seed}: SAH first hits differ from the oracle"
+    assert np.array_equal(a.view(np.uint32), d.view(np.uint32)), f"seed {seed}: SAH + culled differs from the oracle in {(a != d).any(axis=2).sum()} pixels"
 
 
 def _axis_scene():
@@ -130,3 +138,49 @@ def test_axis_aligned_rays_and_nan_slabs(oracle_lib, hip_lib):
     assert so["rays"] == sg["rays"] and so["tri_tests"] == sg["tri_tests"]
     ic, tc, c, _ = _render(hip_lib, _axis_scene(), w, h, True, 3, 1, 4)
     assert np.array_equal(ig, ic) and np.array_equal(b.view(np.uint32), c.view(np.uint32))
+    isa, tsa, d, _ = _render(hip_lib, _axis_scene(), w, h, True, 3, 1, 4, sah=True)     # NaN slabs through the widened SAH tests
+    assert np.array_equal(io, isa) and np.array_equal(a.view(np.uint32), d.view(np.uint32))
+
+
+def _grid_scene(seed):
+    """Boxes with every face on a 0.5 grid around the optical axis of an identity camera, mirrors and glass among
+    them (a reflection off an axis-aligned face keeps a zero direction component, so bounce rays carry them too).
+    Rendered one pixel wide or high, EVERY primary ray has 1/d = inf on an axis and passes exactly along, or a
+    rounding error beside, box faces of both structures."""
+    reset_global_datas()
+    r = np.random.default_rng(1000 + seed)
+    sc = Scene()
+    sc.atmosphere_material = Material(Vector4((1, 1, 1, 1.0), dtype="f4"), transmission=1.0, ior=1.0)
+    mats = [Material(Vector4((0.7, 0.7, 0.7, 1.0), dtype="f4")),
+            Material(Vector4((0.9, 0.9, 0.9, 1.0), dtype="f4"), smoothness=1.0, specularStrength=1.0),
+            Material(Vector4((1, 1, 1, 1.0), dtype="f4"), smoothness=1.0, specularStrength=0.1, transmission=0.9, ior=1.4),
+            Material(Vector4((1, 1, 1, 0.4), dtype="f4")),
+            Material(Vector4((0, 0, 0, 1.0), dtype="f4"), emissionColor=Vector3((1, 1, 1), dtype="f4"), emissionStrength=2.0)]
+    add_mesh(sc, *box_triangles((-4, -4, 12), (4, 4, 12.5)), mats[4])
+    for _ in range(int(r.integers(6, 20))):
+        lo = r.integers((-4, -4, 4), (4, 4, 22), 3) * 0.5
+        hi = lo + r.integers(1, 4, 3) * 0.5
+        add_mesh(sc, *box_triangles(tuple(lo), tuple(hi)), mats[int(r.integers(0, 5))])
+    chunker.BVHGraph.register_all_and_update_node_tri_ids()
+    sc.cam.fov = float(r.choice([30, 50, 90]))
+    sc.cam.near_plane = 1.0
+    sc.cam.antialias_strength = 0.0
+    sc.cam.depth_of_field_strength = 0.0
+    return sc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(8)))
+@pytest.mark.parametrize("size", [(1, 129), (129, 1), (33, 33)])
+def test_zero_direction_components_in_every_mode(oracle_lib, hip_lib, seed, size):
+    w, h = size
+    io, to, a, so = _render(oracle_lib, _grid_scene(seed), w, h, False, 4, 2, 6)
+    assert (io >= 0).any()
+    for sah in (False, True):
+        for cull in (False, True):
+            ig, tg, b, sg = _render(hip_lib, _grid_scene(seed), w, h, cull, 4, 2, 6, sah=sah)
+            what = f"seed {seed} {w}x{h} sah={sah} cull={cull}"
+            assert np.array_equal(io, ig), f"{what}: {(io != ig).sum()} first-hit ids differ"
+            assert np.array_equal(to.view(np.uint32), tg.view(np.uint32)), what
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{what}: {(a != b).any(axis=2).sum()} pixels differ"
+            assert so["rays"] == sg["rays"], what
