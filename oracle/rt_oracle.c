@@ -598,6 +598,30 @@ static void rayTriangle(v3 orig, v3 dir, const Triangle* tri, int hitBehind, Hit
     h->meshIndex = tri->meshIndex;
 }
 
+/* Audit of the product's distance-culling rules (rt_dev_trace.h: culled()), for tests and tools: the interval the
+ * compare ladder ends with for a box the slab test passes, and a count of the queries whose WINNER lies in a leaf
+ * box that those rules could skip: rule (b) exit < 5e-7, rule (a) entry > t_w (1 + 2^-10) + 2^-10 with the winner's
+ * own distance as the best in hand (the boxes above the leaf nest around it and float subtract / multiply are
+ * monotonic, so the leaf is the box of the path that the rules reject first).  rto_cull_audit() switches it on. */
+static int g_audit = 0;
+static unsigned long long g_audit_n[5];              /* queries with a triangle winner; rule (a), rule (b) cases for the winner's leaf box in the
+                                                        reference's tree; the same for the winner's OWN bounding box (inside every box any structure
+                                                        over the same triangles can put it in, so it covers the SAH structure's boxes too) */
+static inline void boxInterval(v3 o, v3 inv, const float* lo, const float* hi, float* tmin_out, float* tmax_out) {
+    float tmin = (lo[0] - o.x) * inv.x, tmax = (hi[0] - o.x) * inv.x, t;
+    if (tmin > tmax) { t = tmin; tmin = tmax; tmax = t; }
+    float tymin = (lo[1] - o.y) * inv.y, tymax = (hi[1] - o.y) * inv.y;
+    if (tymin > tymax) { t = tymin; tymin = tymax; tymax = t; }
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (lo[2] - o.z) * inv.z, tzmax = (hi[2] - o.z) * inv.z;
+    if (tzmin > tzmax) { t = tzmin; tzmin = tzmax; tzmax = t; }
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    *tmin_out = tmin;
+    *tmax_out = tmax;
+}
+
 /* :251-276 */
 static void raySphere(v3 orig, v3 dir, const Sphere* s, HitInfo* h) {
     defaultHit(h);
@@ -625,6 +649,7 @@ static void calculateRayCollision(const rt_ctx* c, const Ray* ray, HitInfo* clos
     v3 inv = V(1.0f / ray->dir.x, 1.0f / ray->dir.y, 1.0f / ray->dir.z);
     HitInfo h;
     int doHitBackside = 0;                           /* :522 uninitialised; false [9.6] (carry variant only) */
+    float win_lo = 0.0f, win_hi = 0.0f, own_lo = 0.0f, own_hi = 0.0f;   /* audit: intervals of the winner's leaf box and of its own box */
     for (int i = 0; i < c->n_spheres; i++) {
         raySphere(ray->origin, ray->dir, &c->spheres[i], &h);
         if (h.dst < 1e-6f) continue;
@@ -664,7 +689,38 @@ static void calculateRayCollision(const rt_ctx* c, const Ray* ray, HitInfo* clos
                 k->tri++;
                 rayTriangle(ray->origin, ray->dir, tri, hitBehind, &h);
                 if (h.dst < 1e-6f) continue;
-                if (h.didHit && h.dst < closest->dst) { *closest = h; closest->material = c->meshes[tri->meshIndex].material; }
+                if (h.didHit && h.dst < closest->dst) {
+                    *closest = h; closest->material = c->meshes[tri->meshIndex].material;
+                    if (g_audit) {
+                        float lo[3], hi[3];
+                        for (int a = 0; a < 3; a++) {
+                            lo[a] = fminf(tri->posA[a], fminf(tri->posB[a], tri->posC[a]));
+                            hi[a] = fmaxf(tri->posA[a], fmaxf(tri->posB[a], tri->posC[a]));
+                        }
+                        boxInterval(ray->origin, inv, node->aabbMin, node->aabbMax, &win_lo, &win_hi);
+                        boxInterval(ray->origin, inv, lo, hi, &own_lo, &own_hi);
+                    }
+                }
+            }
+        }
+    }
+    if (g_audit && closest->didHit && closest->facetId >= 0) {
+        const int rule_b = win_hi < 5e-7f;
+        const float beyond = fmaf(closest->dst, 0x1p-10f, closest->dst) + 0x1p-10f;
+        const int rule_a = win_lo > beyond, own_b = own_hi < 5e-7f, own_a = own_lo > beyond;
+#pragma omp atomic
+        g_audit_n[0]++;
+        if (rule_a || rule_b || own_a || own_b) {
+#pragma omp critical(rto_audit)
+            {
+                g_audit_n[1] += rule_a;
+                g_audit_n[2] += rule_b;
+                g_audit_n[3] += own_a;
+                g_audit_n[4] += own_b;
+                if (g_audit > 1 && (rule_a || rule_b))
+                    fprintf(stderr, "[cull audit] rule %s: t_w %.9g leaf interval [%.9g, %.9g] facet %d o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n",
+                            rule_b ? "b" : "a", closest->dst, win_lo, win_hi, closest->facetId, ray->origin.x, ray->origin.y, ray->origin.z,
+                            ray->dir.x, ray->dir.y, ray->dir.z);
             }
         }
     }
@@ -992,6 +1048,13 @@ int rt_set_cull(rt_ctx* c, int e) { (void)e; return c ? RT_OK : RT_E_ARG; } /* t
 int rt_set_accel(rt_ctx* c, int accel) { (void)accel; return c ? RT_OK : RT_E_ARG; }   /* one structure only: the reference's */
 int rt_set_stream(rt_ctx* c, void* s) { (void)s; return c ? RT_OK : RT_E_ARG; }
 void* rt_stream(rt_ctx* c) { (void)c; return NULL; }
+
+/* mode 0 off, 1 count, 2 count and print each case; out (may be NULL) receives the five counters, which are then reset */
+int rto_cull_audit(int mode, unsigned long long out[5]) {
+    if (out) { memcpy(out, g_audit_n, sizeof g_audit_n); memset(g_audit_n, 0, sizeof g_audit_n); }
+    g_audit = mode;
+    return RT_OK;
+}
 
 /* single-function probes for the known-answer tests ------------------------------------ */
 float rto_random_value(uint32_t* state) { return randomValue(state); }

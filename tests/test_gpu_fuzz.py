@@ -184,3 +184,30 @@ def test_zero_direction_components_in_every_mode(oracle_lib, hip_lib, seed, size
             assert np.array_equal(to.view(np.uint32), tg.view(np.uint32)), what
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{what}: {(a != b).any(axis=2).sum()} pixels differ"
             assert so["rays"] == sg["rays"], what
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_near_axis_rays_culling_differs_only_where_the_audit_says(oracle_lib, hip_lib, seed):
+    """Camera 1e-6 beside the face planes of the grid scene, yawed by 1e-6 degrees: |1/d| = 6e7 on one axis, slab values
+    of +-60 for a box face a micrometre away, bounce origins a rounding error beside box edges.  The exact modes of
+    both structures stay bit-equal to the oracle.  The culling modes may lose a winner only in a query the oracle's
+    audit flags (tests/test_oracle_cull_audit.py), so: no flagged query -> bit-equal, else at most that many pixels."""
+    import ctypes
+
+    from conftest import ORACLE_SO
+    from test_oracle_cull_audit import near_axis_scene
+
+    audit = ctypes.CDLL(str(ORACLE_SO)).rto_cull_audit
+    out = (ctypes.c_ulonglong * 5)()
+    for eps, (w, h) in ((1e-6, (1, 129)), (-3e-7, (129, 1))):
+        audit(ctypes.c_int(1), None)
+        io, to, a, so = _render(oracle_lib, near_axis_scene(seed, 1e-6, eps), w, h, False, 2, 2, 6)
+        audit(ctypes.c_int(0), out)
+        for sah in (False, True):
+            flagged = int(out[3]) + int(out[4]) if sah else int(out[1]) + int(out[2])   # own-box counts cover the SAH boxes
+            ig, tg, b, sg = _render(hip_lib, near_axis_scene(seed, 1e-6, eps), w, h, False, 2, 2, 6, sah=sah)
+            assert np.array_equal(io, ig) and np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"exact mode, sah={sah}"
+            ic, tc, c, _ = _render(hip_lib, near_axis_scene(seed, 1e-6, eps), w, h, True, 2, 2, 6, sah=sah)
+            differing = int((a.view(np.uint32) != c.view(np.uint32)).any(axis=2).sum())
+            assert differing <= flagged, f"seed {seed} eps {eps} sah={sah}: {differing} pixels differ, the audit flags {flagged} queries"
