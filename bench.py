@@ -124,14 +124,17 @@ def main() -> None:
     local_rank %= max(n_dev, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, SUM accumulation, all-reduce, barriers) with
+    # a single rank too: the only way to run the RCCL leg on a one-GPU box (tests/test_gpu_rccl_single_rank.py)
+    dist_on = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST", "0") == "1"
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     # ---- scene + context (inputs resident in HBM before the timed region) ----
@@ -151,7 +154,7 @@ def main() -> None:
     ctx.set_stream(stream.cuda_stream)     # kernels, events and the all-reduce share one stream
     ctx.bind_accum(accum.data_ptr())
 
-    sum_mode = world > 1
+    sum_mode = dist_on
     if not sum_mode:
         first_pass, n_passes, stride, total_passes = 1, PASSES, 1, PASSES
     elif args.scaling == "weak":
@@ -189,7 +192,7 @@ def main() -> None:
     ctx.enable_stats(False)
     cvec = torch.tensor([counts["rays"], counts["box_tests"], counts["tri_tests"], counts["shaded_hits"]],
                         dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(cvec)
     rays_step, box_step, tri_step, hit_step = (float(x) for x in cvec.tolist())
 
@@ -207,7 +210,7 @@ def main() -> None:
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -248,7 +251,7 @@ def main() -> None:
     # for the record: the same frame on the reference's own BVH, culled and exact (rt_set_cull(0));
     # not the headline (the headline mode renders the identical image)
     other = None
-    if world == 1 and not args.strict and not args.reference_structure and not args.no_other_modes and args.workload == "suzanne1080":
+    if not dist_on and not args.strict and not args.reference_structure and not args.no_other_modes and args.workload == "suzanne1080":
         def timed2():
             step()
             torch.cuda.synchronize(dev)
@@ -291,7 +294,7 @@ def main() -> None:
                             f"{BOUNCES} bounces" + (", per GPU" if args.scaling == "weak" else ", whole job"),
                 "structure": "reference BVH" if args.reference_structure else "SAH over the same triangles, reference tie ranks (bit-identical image)",
                 "traversal": "strict (reference box set)" if args.strict else "distance-culled (bit-identical image)",
-                "parallelism": "1 GPU, running mean" if world == 1 else
+                "parallelism": "1 GPU, running mean" if not dist_on else
                                (f"spp-sharded x{world}, {args.scaling} scaling (rank r renders passes r+1, r+1+{world}, ...: {n_passes} on rank 0) "
                                 f"+ RCCL all-reduce of the {WIDTH*HEIGHT*12/1e6:.1f} MB sum"),
                 "rays_per_step": int(rays_step),
@@ -332,7 +335,7 @@ def main() -> None:
             out["rehearsal"] = "RT_BENCH_REHEARSAL=1: 160x90, 4 passes - not a measurement"
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

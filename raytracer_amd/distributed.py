@@ -66,7 +66,7 @@ class ShardedRenderer:
             self.ctx.render(first, n, stride, rays_per_pixel, max_bounces, ffi.RT_ACCUM_SUM)
         if not self.on_gpu:
             self.ctx.sync()
-        if self.world > 1:
+        if self.dist.is_initialized():                           # also with one rank: the same code path as with eight
             self.dist.all_reduce(self.accum, group=self.group)   # RCCL over xGMI on GPU, gloo in tests
         self.ctx.set_accum_passes(total_passes)
         return self.accum / float(total_passes)
@@ -125,14 +125,15 @@ class ShardedAnimation:
         mine = [first_frame + f for f in frames_of_rank(n_frames, self.rank, self.world)]
         out = {}
         rounds = (n_frames + self.world - 1) // self.world
+        grouped = self.dist is not None and self.dist.is_initialized()   # also a group of one rank: same code path as eight
         for k in range(rounds):
             img = None
             if k < len(mine):
                 img = self.render_frame(mine[k])
                 out[mine[k]] = img
-                if on_frame is not None and not (gather and self.world > 1):
+                if on_frame is not None and not (gather and grouped):
                     on_frame(mine[k], img)
-            if gather and self.world > 1:
+            if gather and grouped:
                 got = self._gather_round(img)
                 if self.rank == 0:
                     for r, g in enumerate(got):
@@ -195,7 +196,8 @@ def main(argv=None) -> None:
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    if world > 1:
+    grouped = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST", "0") == "1"   # FORCE: the RCCL leg with one rank (tests)
+    if grouped:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -210,13 +212,13 @@ def main(argv=None) -> None:
     anim = ShardedAnimation(mod, a.height * 16 // 9, a.height, device=local, cull=True, sah=not a.reference_structure,
                             save_frames=a.save)
     anim.render_frame(a.first_frame)                 # warm-up: first launch, allocations
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     got = anim.run(a.frames, gather=a.gather, first_frame=a.first_frame)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     dt = time.perf_counter() - t0
     if anim.rank == 0:
@@ -226,7 +228,7 @@ def main(argv=None) -> None:
                           "config": {"workload": f"{a.height * 16 // 9}x{a.height}, {a.passes} passes x 1 ray/px, {a.bounces} bounces per frame, "
                                                  "host animate hooks + device pose/refit + render + read-back"}}), flush=True)
     anim.close()
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

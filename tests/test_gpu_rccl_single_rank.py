@@ -1,0 +1,88 @@
+"""The RCCL leg of the N > 1 paths on the one GPU a test box has: a process group of ONE rank on the `nccl` backend
+(= RCCL).  Two ranks cannot share a card under RCCL, so this is as far as a one-GPU box can go: it runs
+`init_process_group("nccl", device_id=...)`, the all-reduce of the bound accumulator on the render's stream, the barriers
+and `set_accum_passes` - everything `bench.py --gpus N` and ShardedRenderer / ShardedAnimation do per rank - and checks
+the image against the single-process render.  (World size 2 is covered on CPU with gloo: test_distributed_cpu.py.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(**extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra)
+    return env
+
+
+@pytest.mark.gpu
+def test_bench_takes_the_rccl_path_with_one_rank():
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=_env(RT_BENCH_FORCE_DIST="1", RT_BENCH_REHEARSAL="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL all-reduce" in line["config"]["parallelism"]
+
+
+_SHARDED = r"""
+import sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from conftest import build_suzanne
+from raytracer_amd.distributed import ShardedRenderer
+from raytracer_amd.ffi import RtLib
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+lib = RtLib()
+sc = build_suzanne(0)
+ctx = lib.create(0)
+ctx.load_scene(sc); ctx.load_camera(sc.cam)
+r = ShardedRenderer(ctx, 96, 54)
+mean = r.render(6, 1, 4)
+torch.cuda.synchronize()
+assert ctx.read_accum()[1] == 6
+np.savez({out!r}, total=r.accum.cpu().numpy(), mean=mean.cpu().numpy())
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_sharded_renderer_on_rccl_equals_the_sum_mode_render(tmp_path, hip_lib):
+    from conftest import build_suzanne, make_ctx
+
+    out = tmp_path / "img.npz"
+    code = _SHARDED.format(root=str(ROOT), tests=str(ROOT / "tests"), out=str(out))
+    r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    c = make_ctx(hip_lib, build_suzanne(0), 96, 54)
+    c.render(1, 6, 1, 1, 4, 1)                       # RT_ACCUM_SUM over the same six passes, one rank's shard = all of them
+    want, n = c.read_accum()
+    assert n == 6 and got["total"].max() > 0
+    assert np.array_equal(got["total"].view(np.uint32), want.view(np.uint32))          # the all-reduce of one rank changes nothing
+    assert np.abs(got["mean"] - c.read_mean()).max() <= 1e-6 * max(1.0, float(want.max()))   # torch divides by multiplying with 1/n
+
+
+@pytest.mark.gpu
+def test_animation_runner_gathers_over_rccl_with_one_rank():
+    r = subprocess.run([sys.executable, "-m", "raytracer_amd.distributed", "--frames", "3", "--first-frame", "60", "--height", "90",
+                        "--passes", "2", "--gather"], cwd=str(ROOT), env=_env(RT_BENCH_FORCE_DIST="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["frames"] == 3 and line["frames_held_by_rank0"] == 3 and line["value"] > 0
