@@ -187,6 +187,10 @@ __device__ __forceinline__ bool sah_box_test_any(v3 o, v3 inv, float4 lo, float4
     return box_test(o, inv, make_float4(lo.x - e, lo.y - e, lo.z - e, 0.f), make_float4(hi.x + e, hi.y + e, hi.z + e, 0.f), tmin_out, tmax_out);
 }
 
+// A per-lane boolean as the wave's 64-bit lane mask and back: logic on masks runs on the scalar unit
+__device__ __forceinline__ uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool in_mask(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // Entry distance of a deferred child, kept in 16 bits (LDS is what limits occupancy here): the
 // top half of the binary32 pattern.  Truncation rounds a positive distance down, so the re-check
 // when the child is taken up can only cull less than the full value would; a negative distance
@@ -551,43 +555,57 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
                         const int ref1 = __float_as_int(n0.w), ref2 = __float_as_int(n1.w);
                         float t1a, t1b, t2a, t2b;
-                        bool h1, h2;
+                        // Which child is hit / culled / a leaf / the nearer one is kept as LANE MASKS (64-bit scalars, one
+                        // ballot per compare) and combined on the scalar unit: as booleans the compiler merges them across
+                        // the branches below as 0/1 values in vector registers and compares them again - a dozen vector
+                        // instructions of a step that is bound by vector issue.
+                        uint64_t m_h1, m_h2;
                         if (__ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0) {
-                            h1 = box_test_finite(org, inv, n0, n1, t1a, t1b);
-                            h2 = box_test_finite(org, inv, n2, n3, t2a, t2b);
+                            box_test_finite(org, inv, n0, n1, t1a, t1b);
+                            box_test_finite(org, inv, n2, n3, t2a, t2b);
                             if (sah) {
                                 const float mi = sah_slack(org, inv), mo = sah_org(org);
-                                h1 = sah_widened_hit(t1a, t1b, n2.w, mo, mi);
-                                h2 = sah_widened_hit(t2a, t2b, n3.w, mo, mi);
+                                m_h1 = lane_mask(t1a <= fma_(n2.w + mo, mi, t1b));       // sah_widened_hit
+                                m_h2 = lane_mask(t2a <= fma_(n3.w + mo, mi, t2b));
+                            } else {
+                                m_h1 = lane_mask(t1a <= t1b);
+                                m_h2 = lane_mask(t2a <= t2b);
                             }
                         } else if (!sah) {                          // a lane has an exactly zero direction component
-                            h1 = box_test(org, inv, n0, n1, t1a, t1b);
-                            h2 = box_test(org, inv, n2, n3, t2a, t2b);
+                            m_h1 = lane_mask(box_test(org, inv, n0, n1, t1a, t1b));
+                            m_h2 = lane_mask(box_test(org, inv, n2, n3, t2a, t2b));
                         } else {
                             const float mo = sah_org(org);
-                            h1 = sah_box_test_any(org, inv, n0, n1, n2.w, mo, t1a, t1b);
-                            h2 = sah_box_test_any(org, inv, n2, n3, n3.w, mo, t2a, t2b);
+                            m_h1 = lane_mask(sah_box_test_any(org, inv, n0, n1, n2.w, mo, t1a, t1b));
+                            m_h2 = lane_mask(sah_box_test_any(org, inv, n2, n3, n3.w, mo, t2a, t2b));
                         }
-                        h1 = h1 && ref1 != RT_NONE && !culled<CULL>(t1a, t1b, tv.best_t);
-                        h2 = h2 && ref2 != RT_NONE && !culled<CULL>(t2a, t2b, tv.best_t);
+                        m_h1 &= lane_mask(ref1 != RT_NONE);
+                        m_h2 &= lane_mask(ref2 != RT_NONE);
+                        if (CULL) {                                 // culled(): NaN never culls
+                            const float beyond = fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS;
+                            m_h1 &= ~(lane_mask(t1b < RT_CULL_BEHIND) | lane_mask(t1a > beyond));
+                            m_h2 &= ~(lane_mask(t2b < RT_CULL_BEHIND) | lane_mask(t2a > beyond));
+                        }
                         if (STATS) cnt.box += (ref1 != RT_NONE) + (ref2 != RT_NONE);
-                        // order the children: far one first, so that the near one is taken up first
-                        const bool second_near = t2a < t1a;
+                        const uint64_t m_sn = lane_mask(t2a < t1a);   // far child first, so that the near one is taken up first
+                        const uint64_t m_l1 = lane_mask(ref1 < 0), m_l2 = lane_mask(ref2 < 0);
+                        const uint64_t m_hn = (m_sn & m_h2) | (~m_sn & m_h1), m_hf = (m_sn & m_h1) | (~m_sn & m_h2);
+                        const uint64_t m_ln = (m_sn & m_l2) | (~m_sn & m_l1), m_lf = (m_sn & m_l1) | (~m_sn & m_l2);
+                        const bool second_near = in_mask(m_sn);
                         const int rn = second_near ? ref2 : ref1, rf = second_near ? ref1 : ref2;
                         const float tn = second_near ? t2a : t1a, tf = second_near ? t1a : t2a;
-                        const bool hn = second_near ? h2 : h1, hf = second_near ? h1 : h2;
-                        if (hf && rf < 0) {
+                        if (in_mask(m_hf & m_lf)) {
                             s_leaf[tv.lq * RT_BLOCK] = rf;
                             if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tf);
                             tv.lq++;
                         }
-                        if (hn && rn < 0) {
+                        if (in_mask(m_hn & m_ln)) {
                             s_leaf[tv.lq * RT_BLOCK] = rn;
                             if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tn);
                             tv.lq++;
                         }
-                        const bool in_n = hn && rn >= 0, in_f = hf && rf >= 0;
-                        if (in_n && in_f) {
+                        const uint64_t m_in = m_hn & ~m_ln, m_if = m_hf & ~m_lf;
+                        if (in_mask(m_in & m_if)) {
                             if (!DEEP || tv.sp < S.stack_depth) {
                                 s_stack[tv.sp * RT_BLOCK] = rf;
                                 if (CULL) s_stack_t[tv.sp * RT_BLOCK] = pack_dist(tf);
@@ -598,7 +616,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             }
                             tv.sp++;
                         }
-                        tv.cur = in_n ? rn : (in_f ? rf : RT_NONE);
+                        tv.cur = in_mask(m_in) ? rn : (in_mask(m_if) ? rf : RT_NONE);
                     }
                     // nothing in hand, nothing deferred, no root left: node work is over now, not
                     // one step later (saves one node step per ray)
