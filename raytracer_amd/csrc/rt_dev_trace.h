@@ -283,7 +283,6 @@ struct Trav {
     int lq;           // leaf queue entries
     int k;            // triangle slot in progress, or -1
     uint32_t mask;    // mesh roots still to visit (scenes of up to 32 meshes; larger ones start at the top-level tree)
-    bool node_live;   // node work may remain
     float best_t;
     int best_rank;
 };
@@ -502,16 +501,20 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     constexpr bool sah = SAH;  // the scene was built with RT_ACCEL_SAH (S.tri_box is set)
     bool gated = false;        // SAH: the query in flight is a repeat with the reference-leaf-box gate on every hit
     Trav tv;
-    tv.cur = RT_NONE; tv.sp = 0; tv.lq = 0; tv.k = -1; tv.mask = 0; tv.node_live = false;
+    tv.cur = RT_NONE; tv.sp = 0; tv.lq = 0; tv.k = -1; tv.mask = 0;
     tv.best_t = 1e20f; tv.best_rank = RT_MISS_RANK;
+    // Two per-lane flags of the query in flight, kept as lane masks of the wave (64-bit scalars that are only ever
+    // assigned where the wave's control flow is uniform, so that they stay in scalar registers): node work may remain;
+    // 1/d has a non-finite component (the query takes the reference's compare ladder instead of the min/max form).
+    uint64_t m_live = 0, m_nonfinite = 0;
 
     while (true) {
         // =============== traversal phase: node steps / triangle steps chosen by vote ===============
         while (true) {
-            const bool has_leaf = tv.k >= 0 || tv.lq > 0;
-            const bool can_node = tv.node_live && tv.lq <= LQ - 2;
-            if (mode == M_TRAV && !has_leaf && !tv.node_live) mode = M_PATH;   // the query is finished
-            const uint64_t bN = __ballot(can_node), bT = __ballot(has_leaf);
+            const uint64_t bT = lane_mask(tv.k >= 0) | lane_mask(tv.lq > 0);           // has leaf work
+            const uint64_t bN = m_live & lane_mask(tv.lq <= LQ - 2);                    // can take a node step
+            const bool can_node = in_mask(bN);
+            if (in_mask(lane_mask(mode == M_TRAV) & ~bT & ~m_live)) mode = M_PATH;      // the query is finished
             const int cN = __popcll(bN), cT = __popcll(bT), cAny = __popcll(bN | bT);
             if (cAny == 0) break;
             if (cAny < a.refill_below && __ballot(mode == M_PATH) != 0) break;
@@ -546,8 +549,6 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = 0;   // distance 0: never culled
                                 tv.lq++;
                             }
-                        } else {
-                            tv.node_live = false;
                         }
                     }
                     if (tv.cur != RT_NONE) {                        // :562-584, both children of `cur`
@@ -560,7 +561,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         // the branches below as 0/1 values in vector registers and compares them again - a dozen vector
                         // instructions of a step that is bound by vector issue.
                         uint64_t m_h1, m_h2;
-                        if (__ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0) {
+                        if ((m_nonfinite & lane_mask(true)) == 0) {
                             box_test_finite(org, inv, n0, n1, t1a, t1b);
                             box_test_finite(org, inv, n2, n3, t2a, t2b);
                             if (sah) {
@@ -618,10 +619,10 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         }
                         tv.cur = in_mask(m_in) ? rn : (in_mask(m_if) ? rf : RT_NONE);
                     }
-                    // nothing in hand, nothing deferred, no root left: node work is over now, not
-                    // one step later (saves one node step per ray)
-                    if (tv.cur == RT_NONE && tv.sp == 0 && tv.mask == 0) tv.node_live = false;
                 }
+                // nothing in hand, nothing deferred, no root left: node work is over now, not
+                // one step later (saves one node step per ray)
+                m_live &= ~(bN & lane_mask(tv.cur == RT_NONE) & lane_mask(tv.sp == 0) & lane_mask(tv.mask == 0));
             } else {
                 // triangle burst: stay on triangles while at least half of the lanes that were
                 // traversing at the vote still have leaf work (an upper bound of the lanes a node
@@ -951,12 +952,10 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 if (tlas >= 0) {                                   // many meshes: start at the top-level tree
                     tv.cur = tlas;
                     tv.mask = 0;
-                    tv.node_live = true;
                 } else {
                     tv.cur = RT_NONE;
                     int nearest;
                     tv.mask = root_mask<STATS, CULL>(__builtin_amdgcn_readfirstlane(PS.n_meshes), s_roots, org, inv, tv.best_t, sah, cnt, nearest);
-                    tv.node_live = tv.mask != 0;
                     // the mesh whose root box the ray enters first is visited first (a hit there culls the others)
                     if (nearest >= 0) {
                         const int ref = __float_as_int(s_roots[2 * nearest].w);
@@ -966,6 +965,11 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 mode = M_TRAV;
             }
         }
+        // The wave is converged here: take the two lane masks anew, for the queries that have just started and (to the
+        // same values: node work remains <=> a record in hand, a deferred one or a root left) for those still in flight.
+        // A lane without a query keeps the 1/d of its last one; its bit in m_nonfinite is never looked at.
+        m_live = lane_mask(mode == M_TRAV) & (lane_mask(tv.cur != RT_NONE) | lane_mask(tv.sp > 0) | lane_mask(tv.mask != 0));
+        m_nonfinite = ~(lane_mask(__builtin_isfinite(inv.x)) & lane_mask(__builtin_isfinite(inv.y)) & lane_mask(__builtin_isfinite(inv.z)));
     }
     if (!FIRST_HIT) {
         // every job was folded when its last sample finished (the lane that finishes it asks for the next sample in
