@@ -507,6 +507,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     // assigned where the wave's control flow is uniform, so that they stay in scalar registers): node work may remain;
     // 1/d has a non-finite component (the query takes the reference's compare ladder instead of the min/max form).
     uint64_t m_live = 0, m_nonfinite = 0;
+    uint64_t m_gated = 0;      // SAH: lanes whose query in flight is a repeat with the reference-leaf-box gate on every hit (`gated`)
 
     while (true) {
         // =============== traversal phase: node steps / triangle steps chosen by vote ===============
@@ -630,8 +631,9 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 const int lim = cN + cT;
                 int cTn;
                 do {
-                    if (STATS) { sch.tri_steps++; sch.tri_lanes += __popcll(__ballot(tv.k >= 0 || tv.lq > 0)); }
-                    if (tv.k >= 0 || tv.lq > 0) {
+                    const uint64_t m_leaf = lane_mask(tv.k >= 0) | lane_mask(tv.lq > 0);
+                    if (STATS) { sch.tri_steps++; sch.tri_lanes += __popcll(m_leaf); }
+                    if (in_mask(m_leaf)) {
                         if (tv.k < 0) {                                 // take up the most recently found leaf
                             tv.lq--;
                             const int ref = s_leaf[tv.lq * RT_BLOCK];
@@ -668,8 +670,9 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 // SAH structure, a query that is being repeated (see the path block): a hit
                                 // counts only if the ray passes the box of the triangle's leaf in the
                                 // REFERENCE's tree
-                                if (SAH && __ballot(gated && inside) != 0) {
-                                    if (gated && inside) {
+                                const uint64_t m_chk = SAH ? m_gated & lane_mask(inside) : 0;
+                                if (SAH && m_chk != 0) {
+                                    if (in_mask(m_chk)) {
                                         const float4* rb = (const float4*)((const char*)S.tri_box + ((uint32_t)tv.k << 5));
                                         float ta, tb;
                                         inside = box_test(org, inv, rb[0], rb[1], ta, tb);
@@ -681,7 +684,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             tv.k = __float_as_int(g3.y) > 0 ? tv.k + 1 : -1;
                         }
                     }
-                    cTn = __popcll(__ballot(tv.k >= 0 || tv.lq > 0));
+                    cTn = __popcll(lane_mask(tv.k >= 0) | lane_mask(tv.lq > 0));
                 } while (cTn > 0 && 8 * cTn >= a.burst8 * lim);
             }
         }
@@ -969,6 +972,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
         // same values: node work remains <=> a record in hand, a deferred one or a root left) for those still in flight.
         // A lane without a query keeps the 1/d of its last one; its bit in m_nonfinite is never looked at.
         m_live = lane_mask(mode == M_TRAV) & (lane_mask(tv.cur != RT_NONE) | lane_mask(tv.sp > 0) | lane_mask(tv.mask != 0));
+        m_gated = SAH ? lane_mask(gated) : 0;
         m_nonfinite = ~(lane_mask(__builtin_isfinite(inv.x)) & lane_mask(__builtin_isfinite(inv.y)) & lane_mask(__builtin_isfinite(inv.z)));
     }
     if (!FIRST_HIT) {
