@@ -294,7 +294,7 @@ struct Trav {
 template <bool STATS, bool CULL, bool FINITE>
 __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn, v3 org, v3 inv, float best_t, bool sah, Counters& cnt, int& nearest) {
     uint32_t mask = 0;
-    float near_t = 0.0f;
+    float near_t = __builtin_inff();      // (an entry distance of +inf or NaN leaves `nearest` unset: the order is a heuristic only)
     nearest = -1;
     const float mi = sah_slack(org, inv), mo = sah_org(org);
     // One box per trip, not unrolled: the kernel is issue bound, so overlapping the LDS latency
@@ -321,7 +321,7 @@ __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn
             const bool take = real && h && !culled<CULL>(ta, tb, best_t);
             if (STATS) cnt.box += real;
             mask |= take ? (1u << (b0 + u)) : 0u;
-            const bool nearer = take && (nearest < 0 || ta < near_t);
+            const bool nearer = take && ta < near_t;
             nearest = nearer ? b0 + u : nearest;
             near_t = nearer ? ta : near_t;
         }
