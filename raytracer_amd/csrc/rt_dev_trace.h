@@ -456,15 +456,17 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     const DevScene& PS = P.scene;
     const DevCamera& cam = P.cam;
     const MatDev& atmo = P.atmo;
-    // per-lane column: node stack entries [0, stack_depth), leaf queue [stack_depth, stack_depth + LQ);
+    // per-lane column: leaf queue entries [0, LQ), node stack entries [LQ, LQ + stack_depth);
     // entry e at s_stack[e * RT_BLOCK].  CULL builds keep the entry distance of each deferred
     // child in a second plane so that it can be re-culled when it is taken up.
     constexpr int LQ = RT_LQ_OF(SAH);
     const int n_ent = S.stack_depth + LQ;
-    int* s_stack = (int*)(s_mem + n_root4 + RT_PC_F4) + threadIdx.x;
-    unsigned short* s_stack_t = (unsigned short*)((int*)(s_mem + n_root4 + RT_PC_F4) + (size_t)n_ent * RT_BLOCK) + threadIdx.x;
-    int* s_leaf = s_stack + (size_t)S.stack_depth * RT_BLOCK;
-    unsigned short* s_leaf_t = s_stack_t + (size_t)S.stack_depth * RT_BLOCK;
+    // (the leaf queue comes FIRST in a column: the node stack then starts at a compile-time offset from the same base
+    // register, where "stack first" needs a second base register per plane for a run-time stack depth)
+    int* s_leaf = (int*)(s_mem + n_root4 + RT_PC_F4) + threadIdx.x;
+    unsigned short* s_leaf_t = (unsigned short*)((int*)(s_mem + n_root4 + RT_PC_F4) + (size_t)n_ent * RT_BLOCK) + threadIdx.x;
+    int* s_stack = s_leaf + (size_t)LQ * RT_BLOCK;
+    unsigned short* s_stack_t = s_leaf_t + (size_t)LQ * RT_BLOCK;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -476,7 +478,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     // taken from a launch-wide counter by whichever wave runs dry; a lane whose sample is finished
     // takes the next one of its wave's job (pass-major), so no lane waits for a slower neighbour and
     // the launch ends within one job's time on every SIMD.
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: say so, or every address derived from it sits in vector registers
     WaveJobs* wj = &s_pc->wj[wave];
     if (lane == 0) { wj->done[0] = wj->done[1] = 0; wj->expected[0] = wj->expected[1] = 0; }
     // (job shape and staging base are read from the LDS argument copy where the path block needs them: scalar
@@ -489,12 +491,13 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     int mode = M_PATH;
     bool have = false;         // holds a sample: pixel pxy, staging element `elem` of its wave (slot * job_cap + pass * tile pixels + pixel of the tile)
     uint32_t pxy = 0, elem = 0;
-    int s = 0;                 // paths of the current sample started
+    uint32_t sb = 0;           // low half: paths of the current sample started; high half: bounce of the path in flight
+                               // (one register: the path block is where this kernel runs out of them; both <= 65535, rt_render checks)
     uint32_t rng = 0;
     bool fresh = true;         // no path in flight: the path block generates a camera sample
     v3 org = V3(0.f, 0.f, 0.f), dir = V3(0.f, 0.f, 1.f), inv = V3(0.f, 0.f, 0.f);
     v3 thr = V3(1.f, 1.f, 1.f), inc = V3(0.f, 0.f, 0.f);
-    int prev_id = -1, prev_mat = -1, bounce = 0;
+    int prev_id = -1, prev_mat = -1;
     float ior = 1.0f;
     bool in_solid = false;
     int hb_key = 0;            // hitBehind test of the ray in flight: the mesh it is inside, or 0 (set at query start)
@@ -712,7 +715,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         P.ts[pix] = tv.best_t;
                         have = false;
                         fresh = true;
-                        s = 0;
+                        sb = 0;
                     }
                 } else if (tv.best_rank == RT_MISS_RANK) {         // miss: environment light is vec3(0) (:279-282)
                     fresh = true;
@@ -755,7 +758,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     if (!redo && alpha < 0.99999f) {                        // :725-736
                         if (random_value(rng) > alpha) {
                             passthrough = true;
-                            if (bounce == P.max_bounces) ended = true;
+                            if ((sb >> 16) == (uint32_t)P.max_bounces) ended = true;
                             else { org = hit_point; prev_id = hit_id; prev_mat = hit_mat; }
                         }
                     }
@@ -802,7 +805,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             spec_dir = reflect3(dir, nrm);
                             diffuse = -diffuse;
                         }
-                        if (bounce == P.max_bounces) ended = true;
+                        if ((sb >> 16) == (uint32_t)P.max_bounces) ended = true;
                         else {
                             org = hit_point;
                             if (specular) {
@@ -819,15 +822,15 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         }
                     }
                     if (ended) fresh = true;
-                    else { bounce += !redo; start = true; }
+                    else { sb += redo ? 0u : 0x10000u; start = true; }
                 }
                 if (fresh && !FIRST_HIT) {                         // the path is over (:989): totalIncomingLight += inc
                     // the sample's running sum lives in the staging slot of its job (three fewer live registers):
                     // element (pass, pixel of the tile); fold_job divides by RAYS_PER_PIXEL (:1009)
                     float* o = stage_of_wave(P, wave) + (size_t)elem * 3;
-                    const v3 sum = s == 1 ? V3(0.f, 0.f, 0.f) : V3(o[0], o[1], o[2]);
+                    const v3 sum = (sb & 0xffffu) == 1u ? V3(0.f, 0.f, 0.f) : V3(o[0], o[1], o[2]);
                     o[0] = sum.x + inc.x; o[1] = sum.y + inc.y; o[2] = sum.z + inc.z;
-                    if (s == P.rays_per_pixel) { s = 0; have = false; completed = true; }   // the sample is complete (:1008-1010)
+                    if ((sb & 0xffffu) == (uint32_t)P.rays_per_pixel) { sb = 0; have = false; completed = true; }   // the sample is complete (:1008-1010)
                 }
             }
             need = fresh && !have;
@@ -919,8 +922,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     in_solid = false;
                     thr = V3(1.f, 1.f, 1.f);
                     inc = V3(0.f, 0.f, 0.f);
-                    bounce = 0;
-                    s++;
+                    sb = (sb & 0xffffu) + 1u;                            // bounce = 0, one more path of the sample
                     fresh = false;
                     start = true;
                 }

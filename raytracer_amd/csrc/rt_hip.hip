@@ -1276,6 +1276,7 @@ static int render_impl(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t st
     int rc = check_ready(c);
     if (rc) return rc;
     if (rpp < 1 || max_bounces < 0 || stride < 1) return fail(c, RT_E_ARG, "bad sampling arguments");
+    if (rpp > 65535 || max_bounces > 65535) return fail(c, RT_E_LIMIT, "rays_per_pixel and max_bounces are limited to 65535");
     if (flags != RT_ACCUM_MEAN && flags != RT_ACCUM_SUM) return fail(c, RT_E_ARG, "bad flags");
     if (flags == RT_ACCUM_MEAN && stride != 1) return fail(c, RT_E_ARG, "running mean needs pass_stride 1");
     // raytracer.fs.glsl:931-935: a pass whose index exceeds MAX_CYCLES returns the previous frame
