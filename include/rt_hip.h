@@ -163,7 +163,8 @@ int rt_bind_accum(rt_ctx* ctx, void* device_ptr);
 /* replaces: render_with_chunk's pass loop (application.py:1190-1207): passes
  * first_pass, first_pass+stride, ... (n_passes of them) are the `frameNumber` values that
  * seed the per-pixel RNG (raytracer.fs.glsl:956-957); rays_per_pixel / max_bounces are the
- * RAYS_PER_PIXEL / MAX_BOUNCES uniforms (application.py:1182-1183). */
+ * RAYS_PER_PIXEL / MAX_BOUNCES uniforms (application.py:1182-1183); each is limited to 65535
+ * (RT_E_LIMIT beyond: the kernel keeps both counters of a path in one register). */
 int rt_render(rt_ctx* ctx, uint32_t first_pass, uint32_t n_passes, uint32_t pass_stride,
               int rays_per_pixel, int max_bounces, int flags);
 

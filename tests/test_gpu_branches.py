@@ -116,3 +116,19 @@ def test_tiny_jobs_make_lanes_wait_for_a_staging_slot(hip_lib, oracle_lib, monke
             got = run(hip_lib, *case)
             assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), f"case {case}, RT_JOB_SAMPLES={job}: {(ref != got).any(axis=2).sum()} pixels differ"
     monkeypatch.delenv("RT_JOB_SAMPLES", raising=False)
+
+
+@pytest.mark.gpu
+def test_sampling_counters_limit(hip_lib):
+    """rays_per_pixel and max_bounces share one register in the kernel (16 bits each): the largest values render, larger
+    ones are refused with RT_E_LIMIT (include/rt_hip.h)."""
+    from conftest import build_suzanne, make_ctx
+    from raytracer_amd.ffi import RtError
+
+    c = make_ctx(hip_lib, build_suzanne(0), 16, 9)
+    c.render(1, 1, 1, 2, 65535, 0)                  # paths end long before (no surface reflects everything)
+    assert np.isfinite(c.read_mean()).all()
+    for rpp, bounces in ((65536, 4), (1, 65536)):
+        with pytest.raises(RtError) as e:
+            c.render(1, 1, 1, rpp, bounces, 0)
+        assert e.value.args[0] == -4 or "65535" in str(e.value)
