@@ -809,9 +809,9 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         else {
                             org = hit_point;
                             if (specular) {
-                                const float sa = m->smoothness, sb = 1.0f - sa;
-                                dir = V3(diffuse.x * sb + spec_dir.x * sa, diffuse.y * sb + spec_dir.y * sa,
-                                         diffuse.z * sb + spec_dir.z * sa);
+                                const float sa = m->smoothness, sd = 1.0f - sa;
+                                dir = V3(diffuse.x * sd + spec_dir.x * sa, diffuse.y * sd + spec_dir.y * sa,
+                                         diffuse.z * sd + spec_dir.z * sa);
                                 thr = thr * V3(m->specularColor[0], m->specularColor[1], m->specularColor[2]);
                             } else {
                                 dir = diffuse;
