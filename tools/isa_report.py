@@ -118,9 +118,10 @@ if len(groups) >= 2:
     for name, k in (("triangle step (one triangle of a leaf per lane)", tri_k), ("node step (one interior record = two child boxes per lane)", node_k)):
         a, b = block(k)
         print(f"{name}: asm lines {a}..{b}: {count(a, b)}")
-    print("  (the node step's range holds BOTH forms of the slab test: the min/max form every wave with finite 1/d takes - 121 VALU + 73 SALU on that path -")
+    print("  (the node step's range holds BOTH forms of the slab test: the min/max form every wave with finite 1/d takes")
     print("   and the reference's compare-and-swap ladder for a wave with an exactly zero direction component)")
     a, b = block(node_k)
     print(f"path block + sample hand-out + query start (everything after the traversal loop): {count(b, len(body))}")
-print("\nDynamic counts per executed block, fitted from SQ_INSTS_VALU / SQ_INSTS_SALU against the wave-level step counters (tools/fit_steps.sh, DESIGN.md 8):")
+print("\nDynamic counts per executed block, fitted from SQ_INSTS_VALU / SQ_INSTS_SALU against the wave-level step counters (tools/fit_steps.sh, DESIGN.md 8),")
+print("BEFORE the lane-mask bookkeeping of round 2 (after it the three-threshold fit is ill-conditioned; per launch: see the counters below):")
 print("  node step 131 VALU + 71 SALU, triangle step 89 + 60, path block 1097 + 368 (SAH structure, culled)")
