@@ -17,6 +17,28 @@ which = os.environ.get('RT_SCENE', 'suzanne')          # suzanne | suzanne5 (991
 if which == 'dragon':
     from raytracer_amd.scripts.scenes import dragon_scene as D
     sc = D.build()
+elif which == 'dragon_merged':
+    # experiment: the dragon scene's triangles as ONE mesh (one SAH tree over everything instead of a top-level tree over
+    # 192 per-mesh trees).  Materials are then all the dragon's, so the image differs: step counts and time only.
+    import numpy as np
+    from raytracer_amd.scripts.classes import Mesh, Scene
+    from raytracer_amd.scripts.scenes import chunker, dragon_scene as D
+    from raytracer_amd.scripts.numba_utils import classes as _nb
+    from raytracer_amd.scripts.scenes.utils import read_obj, reset_global_datas
+    src = D.build()
+    files, mat, atmo, pose, cam = src.mesh_files, src.meshes[0].material, src.atmosphere_material, src.meshes[0].csys, src.cam
+    reset_global_datas()
+    sc = Scene()
+    sc.atmosphere_material = atmo
+    mesh = Mesh(material=mat)
+    parts = [read_obj(f"{D.DRAGON_DIR}/{f}") for f in files]
+    mesh.triangles = _nb.TriangleSet(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), mesh.id, 0)
+    _nb.add_to_all_triangles(mesh.triangles)
+    mesh.csys = pose
+    sc.meshes.append(mesh)
+    chunker.chunk_mesh_bvh(mesh)
+    chunker.BVHGraph.register_all_and_update_node_tri_ids()
+    sc.cam = cam
 elif which.startswith('suzanne') and which != 'suzanne':
     sc = S.build(subdivide=int(which[7:]), lib=lib)
 else:
