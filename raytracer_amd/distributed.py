@@ -118,6 +118,60 @@ class ShardedAnimation:
         self.prog.calculate_frame(self.app.display_scene)
         return self.prog.last_image
 
+    def run_pipelined(self, n_frames: int, first_frame: int = 0, on_frame=None) -> dict:
+        """This rank's frames like ``run`` (no gather), with the read-back of frame k overlapped with the host work and
+        the render of frame k+1: two device accumulators bound in turn (``rt_bind_accum``), the render on torch's
+        stream, an asynchronous copy into pinned host memory behind it, and the host only waits for a frame when the
+        next one is already queued.  Same images bit for bit (the accumulator of RT_ACCUM_MEAN is the mean).  HIP
+        backend only: the checker library renders on the host, where there is nothing to overlap.  The process must have
+        let torch initialise the GPU before the library was loaded, as the runner below does."""
+        import torch
+
+        prog, ctx = self.prog, self.prog.ctx
+        if ctx.lib.backend != "hip" or prog.save_frames:
+            return self.run(n_frames, first_frame=first_frame, on_frame=on_frame)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        acc = [torch.zeros((self.height, self.width, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+        host = [torch.empty((self.height, self.width, 3), dtype=torch.float32).pin_memory() for _ in range(2)]
+        done = [None, None]
+        frame_in = [None, None]
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        out = {}
+
+        def collect(b):
+            if frame_in[b] is None:
+                return
+            done[b].synchronize()
+            img = host[b].numpy().copy()
+            out[frame_in[b]] = img
+            if on_frame is not None:
+                on_frame(frame_in[b], img)
+            frame_in[b] = None
+
+        prog.defer_readback = True
+        try:
+            mine = [first_frame + f for f in frames_of_rank(n_frames, self.rank, self.world)]
+            for k, frame in enumerate(mine):
+                b = k & 1
+                collect(b)                                   # the frame that used this pair of buffers two frames ago
+                ctx.bind_accum(acc[b].data_ptr())
+                prog.app_frame_counter = frame - 1
+                prog.calculate_frame(self.app.display_scene)   # animate, upload, render: all queued, nothing read back
+                host[b].copy_(acc[b], non_blocking=True)
+                done[b] = torch.cuda.Event()
+                done[b].record()
+                frame_in[b] = frame
+                collect(1 - b)                               # the previous frame finishes while this one renders
+            collect(0)
+            collect(1)
+        finally:
+            prog.defer_readback = False
+            torch.cuda.synchronize(dev)
+            ctx.bind_accum(None)                             # back to the context's own accumulator and stream
+            ctx.set_stream(None)
+        prog.last_image = out[mine[-1]] if mine else None
+        return out
+
     def run(self, n_frames: int, gather: bool = False, first_frame: int = 0, on_frame=None) -> dict:
         """Render frames first_frame .. first_frame+n_frames-1, sharded round-robin.  Returns {frame:
         image} of this rank's frames; with ``gather`` rank 0 returns every frame (other ranks their own).
@@ -179,6 +233,7 @@ def main(argv=None) -> None:
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--save", action="store_true", help="write PNG/EXR/.npy of every frame at the reference's cadence")
     ap.add_argument("--gather", action="store_true", help="collect the finished frames on rank 0")
+    ap.add_argument("--pipeline", action="store_true", help="overlap the read-back of a frame with the next frame (run_pipelined; no gather)")
     ap.add_argument("--reference-structure", action="store_true")
     a = ap.parse_args(argv)
 
@@ -216,7 +271,10 @@ def main(argv=None) -> None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    got = anim.run(a.frames, gather=a.gather, first_frame=a.first_frame)
+    if a.pipeline and not a.gather:
+        got = anim.run_pipelined(a.frames, first_frame=a.first_frame)
+    else:
+        got = anim.run(a.frames, gather=a.gather, first_frame=a.first_frame)
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()

@@ -370,7 +370,8 @@ class RayTracerDynamic(ProgramABC):
             cam.cycle_counter = nxt
             if self.save_frames and (nxt < 10 or nxt % 10 == 0):
                 self.save_frame(None, self.app_frame_counter, nxt)
-        self.last_image = self.ctx.read_mean()
+        if not getattr(self, "defer_readback", False):    # a pipelined runner copies the frame back itself, asynchronously
+            self.last_image = self.ctx.read_mean()
         if self.is_scene_static:
             cam.cycle_counter += 1
         else:

@@ -71,3 +71,54 @@ def test_keyframes_exact_and_bench_mode_against_the_oracle(oracle_lib, hip_lib):
     assert 0.0 in alpha_seen and 1.0 in alpha_seen and any(0.0 < a < 1.0 for a in alpha_seen)   # all three alpha regimes were rendered
     for c in ctxs:
         c.close()
+
+
+_PIPE_CHILD = r"""
+import sys, types
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+import torch
+torch.cuda.set_device(0)
+torch.zeros(1, device="cuda")                      # torch brings the HIP runtime up first (INTEGRATION.md 4)
+from raytracer_amd.distributed import ShardedAnimation
+from raytracer_amd.ffi import RtLib
+from raytracer_amd.scripts.animate import FrameAnimation
+from raytracer_amd.scripts.scenes import final_scene_numba as S
+
+def module():
+    sc = S.build()
+    def override(cam, i):
+        cam.passes_per_frame, cam.bounces_per_ray = 3, 4
+    sc.animations.append(FrameAnimation(sc.cam, override))
+    return types.SimpleNamespace(scene=sc, get_frame_number=S.get_frame_number, __file__=S.__file__)
+
+lib = RtLib()
+seq = ShardedAnimation(module(), 96, 54, lib=lib, cull=True, sah=True)
+want = seq.run(5, first_frame=118)
+seq.close()
+pipe = ShardedAnimation(module(), 96, 54, lib=lib, cull=True, sah=True)
+seen = []
+got = pipe.run_pipelined(5, first_frame=118, on_frame=lambda f, img: seen.append(f))
+assert sorted(got) == sorted(want) == [118, 119, 120, 121, 122] and seen == [118, 119, 120, 121, 122], (sorted(got), seen)
+for f in want:
+    assert want[f].max() > 0 and np.array_equal(want[f].view(np.uint32), got[f].view(np.uint32)), f
+assert not np.array_equal(want[118], want[122])
+again = pipe.render_frame(120)                     # the context's own accumulator and stream again
+assert np.array_equal(again.view(np.uint32), want[120].view(np.uint32))
+pipe.close()
+print("PIPELINE_OK")
+"""
+
+
+@pytest.mark.gpu
+def test_pipelined_animation_equals_the_sequential_one():
+    """ShardedAnimation.run_pipelined (two accumulators bound in turn, asynchronous read-back behind the render on torch's
+    stream) returns the frames of ShardedAnimation.run bit for bit, and leaves the context usable afterwards.  In a child
+    interpreter that initialises torch first, like tests/test_gpu_torch_binding.py."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, "-c", _PIPE_CHILD, str(root)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PIPELINE_OK" in r.stdout, r.stderr[-3000:]
