@@ -221,7 +221,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES) void k_trace(TraceArgs a) {
 // runs on holds its own copy until the process ends; its DEVICE address is taken once per context
 // with hipGetSymbolAddress (rt_create) - in host code the name `scratch` is only a stand-in.
 //   [0, 256)                                 work counter
-//   [256, 256 + RT_STATIC_OVF_BYTES)         stack_ovf (int2 per deep entry and launch lane)
+//   [256, 256 + RT_STATIC_OVF_BYTES)         stack_ovf (int per deep entry and launch lane)
 //   [256 + RT_STATIC_OVF_BYTES, end)         stage (per wave: 2 slots x job_cap float3)
 #define RT_STATIC_OVF_BYTES ((size_t)16 << 20)
 #define RT_STATIC_STAGE_OFF ((size_t)256 + RT_STATIC_OVF_BYTES)
@@ -392,7 +392,7 @@ struct rt_ctx {
     int n_cus = 0;
     size_t lds_per_cu = 160 * 1024;
     int stack_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // per k_trace variant: node stack entries in LDS for the scene in place
-    DevBuf<int2> stack_ovf;               // deeper entries (rare): (stack_depth - cap) x launch lanes
+    DevBuf<int> stack_ovf;                // deeper entries (rare): (stack_depth - cap) x launch lanes
     size_t stack_ovf_n = 0;
     unsigned char* static_scratch = nullptr;   // device address of `scratch` on this context's GPU (hipGetSymbolAddress)
     bool launch_static = false;           // the launch in preparation belongs to rt_render_static: nothing may be allocated
@@ -626,33 +626,37 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
 }
 
 // dynamic LDS of a k_trace launch: root table + kernel-argument copy + per-lane node stack and leaf
-// queue (+ the entry-distance plane when culling).  The node stack of a deep tree (dragon scene:
+// queue (+ a 16-bit entry-distance plane for the leaf queue when culling).  The node stack of a deep tree (dragon scene:
 // 29 levels with the top-level tree = 48 KB per workgroup) would leave 3 workgroups per CU, so
 // only as many entries as keep RT_WAVES workgroups resident live in LDS; the rare deeper ones go
 // to `stack_ovf` in global memory (DEEP instantiations; a scene whose whole stack fits runs the
 // instantiation without that test).
+size_t trace_lds_bytes(const rt_ctx* c, int cap, bool cull, bool sah) {
+    const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_meshes) + RT_PC_F4) * sizeof(float4);
+    const size_t lq = RT_LQ_OF(sah);
+    return fixed + ((size_t)cap + lq) * RT_BLOCK * 4 + (cull ? lq * RT_BLOCK * 2 : 0);
+}
+
 template <bool STATS, bool CULL, bool FIRST, bool SAH, bool DEEP>
 int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
-    const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_meshes) + RT_PC_F4) * sizeof(float4);
-    const size_t per_ent = (size_t)RT_BLOCK * (CULL ? 6 : 4);
     if (c->blocks_per_cu[key] <= 0) {
         int nb = 0, nb_best = 0;
         for (;;) {
-            HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, fixed + (size_t)(cap + RT_LQ_OF(SAH)) * per_ent));
+            HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, trace_lds_bytes(c, cap, CULL, SAH)));
             if (!DEEP || nb >= RT_WAVES || cap <= RT_MIN_STACK_LDS || c->stack_lds_force > 0) break;
             // lds_stack_entries guessed the allocation granule wrong, or registers are the limit
             if (nb_best == 0)
-                HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_best, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, fixed + (size_t)(RT_MIN_STACK_LDS + RT_LQ_OF(SAH)) * per_ent));
+                HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_best, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, trace_lds_bytes(c, RT_MIN_STACK_LDS, CULL, SAH)));
             if (nb >= nb_best) break;
             cap--;
         }
-        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (%d mesh roots)", fixed + (size_t)(cap + RT_LQ_OF(SAH)) * per_ent, c->n_meshes);
+        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (%d mesh roots)", trace_lds_bytes(c, cap, CULL, SAH), c->n_meshes);
         c->blocks_per_cu[key] = nb;
         c->stack_lds[key] = cap;
-        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] k_trace variant %d: %d of %d node stack entries in LDS, %zu bytes of LDS, %d workgroups per CU\n", key, cap, c->stack_depth, fixed + (size_t)(cap + RT_LQ_OF(SAH)) * per_ent, nb);
+        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] k_trace variant %d: %d of %d node stack entries in LDS, %zu bytes of LDS, %d workgroups per CU\n", key, cap, c->stack_depth, trace_lds_bytes(c, cap, CULL, SAH), nb);
     }
     cap = c->stack_lds[key];
-    const size_t lds = fixed + (size_t)(cap + RT_LQ_OF(SAH)) * per_ent;
+    const size_t lds = trace_lds_bytes(c, cap, CULL, SAH);
     // every wave takes whole chunks: no point in more waves than chunks
     unsigned grid = std::max(1u, (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_jobs + 3) / 4));
     TraceArgs b = a;
@@ -661,7 +665,7 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     if (c->launch_static) {
         // rt_render_static: the deep entries live in the static scratch; a scene whose deep entries
         // do not fit for a full grid runs on as many workgroups as they fit for
-        const size_t cap_ent = RT_STATIC_OVF_BYTES / sizeof(int2);
+        const size_t cap_ent = RT_STATIC_OVF_BYTES / sizeof(int);
         if (deep * RT_BLOCK > cap_ent) return fail(c, RT_E_LIMIT, "rt_render_static: BVH too deep for the static scratch (%zu entries per lane beyond LDS)", deep);
         if (deep) grid = (unsigned)std::min<size_t>(grid, cap_ent / (deep * RT_BLOCK));
         // ... and the staging slots of its waves: 2 x job_cap float3 each
@@ -670,7 +674,7 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
             if (per_block > RT_STATIC_SCRATCH_BYTES - RT_STATIC_STAGE_OFF) return fail(c, RT_E_LIMIT, "rt_render_static: a job of %u samples does not fit the static scratch", a.job_cap);
             grid = (unsigned)std::min<size_t>(grid, (RT_STATIC_SCRATCH_BYTES - RT_STATIC_STAGE_OFF) / per_block);
         }
-        b.stack_ovf = (int2*)(c->static_scratch + 256);
+        b.stack_ovf = (int*)(c->static_scratch + 256);
         b.work_counter = (unsigned int*)c->static_scratch;
         b.stage = (float*)(c->static_scratch + RT_STATIC_STAGE_OFF);
     } else {
@@ -702,13 +706,11 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
 // node stack entries kept in LDS: all of them if RT_WAVES workgroups per CU still fit, else as many as do
 int lds_stack_entries(const rt_ctx* c) {
     if (c->stack_lds_force > 0) return std::min(c->stack_depth, c->stack_lds_force);
-    const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_meshes) + RT_PC_F4) * sizeof(float4);
-    const size_t per_ent = (size_t)RT_BLOCK * (c->cull ? 6 : 4);
     // LDS is handed out in 1280-byte granules on gfx950 (160 KB / 128): budget per workgroup rounded down to that
     const size_t budget = (c->lds_per_cu / RT_WAVES) / 1280 * 1280;
-    const int lq = RT_LQ_OF(c->scene_is_sah);
-    if (fixed + (size_t)(c->stack_depth + lq) * per_ent <= budget) return c->stack_depth;
-    const int fit = (int)((budget > fixed ? budget - fixed : 0) / per_ent) - lq;
+    if (trace_lds_bytes(c, c->stack_depth, c->cull, c->scene_is_sah) <= budget) return c->stack_depth;
+    const size_t base = trace_lds_bytes(c, 0, c->cull, c->scene_is_sah);
+    const int fit = (int)((budget > base ? budget - base : 0) / ((size_t)RT_BLOCK * 4));
     return std::max(RT_MIN_STACK_LDS, std::min(c->stack_depth, fit));
 }
 
