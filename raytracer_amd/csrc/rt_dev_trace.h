@@ -191,9 +191,9 @@ __device__ __forceinline__ bool sah_box_test_any(v3 o, v3 inv, float4 lo, float4
 __device__ __forceinline__ uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ __forceinline__ bool in_mask(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
-// Entry distance of a deferred child, kept in 16 bits (LDS is what limits occupancy here): the
+// Entry distance of a queued leaf, kept in 16 bits (LDS is what limits occupancy here): the
 // top half of the binary32 pattern.  Truncation rounds a positive distance down, so the re-check
-// when the child is taken up can only cull less than the full value would; a negative distance
+// when the leaf is taken up can only cull less than the full value would; a negative distance
 // (the origin is inside or past the box) moves towards zero but keeps its sign, and no
 // non-positive distance is ever beyond the best hit; a NaN produced by arithmetic has its quiet
 // bit (bit 22) set and stays NaN (never culls).
