@@ -100,6 +100,7 @@ struct DevScene {
     int n_spheres;
     int stack_depth;      // node stack entries a lane has in LDS (rt_hip.hip sizes it for full occupancy); DEEP builds: deeper entries go to stack_ovf
     int tlas_root;        // > 32 meshes: record of the top-level tree over the mesh roots; else -1 (roots in LDS)
+    int rank_lds;         // entries of rank_slot that k_trace copies into LDS (all of them or 0: rt_hip.hip::trace_lds_bytes)
 };
 
 struct DevCamera {
@@ -448,6 +449,19 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     float4* s_roots = s_mem;
     const int n_root4 = S.tlas_root >= 0 ? 0 : 2 * S.n_meshes;
     for (int i = threadIdx.x; i < n_root4; i += RT_BLOCK) s_roots[i] = S.roots[i];
+    // ... the mesh materials of the same scenes (80 B each): the path block reads the hit material after the winner's
+    // record, a dependent memory round trip that an LDS copy shortens ...
+    const int n_mat4 = S.tlas_root >= 0 ? 0 : 5 * S.n_meshes;
+    float4* s_mats4 = s_mem + n_root4;
+    for (int i = threadIdx.x; i < n_mat4; i += RT_BLOCK) s_mats4[i] = ((const float4*)S.mats)[i];
+    const MatDev* s_mats = n_mat4 ? (const MatDev*)s_mats4 : S.mats;
+    s_mem += n_mat4;
+    // ... and, for a small SAH scene, the rank -> slot table: the first of the path block's dependent loads (winner's
+    // rank -> slot -> its records -> its material), each a round trip to the L2 otherwise
+    int* s_rank = (int*)(s_mem + n_root4);
+    for (int i = threadIdx.x; i < S.rank_lds; i += RT_BLOCK) s_rank[i] = S.rank_slot[i];
+    const int* rank_slot = S.rank_lds ? s_rank : S.rank_slot;
+    s_mem += (S.rank_lds + 3) / 4;
     // camera and atmosphere constants: read from LDS where the path block needs them, instead of
     // ~50 scalar registers held (and spilled) across the traversal loop
     PathConsts* s_pc = (PathConsts*)(s_mem + n_root4);
@@ -688,7 +702,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     if (tv.best_rank != RT_MISS_RANK) {
                         if (tv.best_rank < 0) id = -2 - (tv.best_rank - RT_SPHERE_RANK);
                         else {
-                            const int slot = PS.rank_slot[tv.best_rank];
+                            const int slot = SAH ? rank_slot[tv.best_rank] : tv.best_rank;   // (reference structure: slots are in rank order)
                             id = PS.slot_id[slot];
                             if (SAH && !gated) redo = !ref_leaf_box_passes(PS, slot, org, inv) || P.recheck_all != 0;
                         }
@@ -717,7 +731,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         normal = normalize3(hit_point - V3(sph.position[0], sph.position[1], sph.position[2]));
                         hit_mat = 256 + si;
                     } else {
-                        const int slot = PS.rank_slot[tv.best_rank];
+                        const int slot = SAH ? rank_slot[tv.best_rank] : tv.best_rank;
                         const float4* g = S.tri_geo + 4 * (size_t)slot;
                         const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
                         const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
@@ -737,7 +751,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         hit_mat = __float_as_int(na.w);
                     }
                     if (STATS) cnt.hits += !redo;
-                    const MatDev* m = material_of(PS, hit_mat);
+                    const MatDev* m = hit_mat < 256 ? &s_mats[hit_mat] : &PS.spheres[hit_mat - 256].material;
                     const float alpha = m->color[3];
                     bool ended = false, passthrough = redo;   // a query to be repeated changes nothing here
                     if (!redo && alpha < 0.99999f) {                        // :725-736
@@ -771,7 +785,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 float pc0 = atmo.color[0], pc1 = atmo.color[1], pc2 = atmo.color[2];
                                 float pc3 = atmo.color[3], ptr = atmo.transmission;
                                 if (prev_mat >= 0) {
-                                    const MatDev* pm = material_of(PS, prev_mat);
+                                    const MatDev* pm = prev_mat < 256 ? &s_mats[prev_mat] : &PS.spheres[prev_mat - 256].material;
                                     pc0 = pm->color[0]; pc1 = pm->color[1]; pc2 = pm->color[2]; pc3 = pm->color[3];
                                     ptr = pm->transmission;
                                 }

@@ -583,12 +583,14 @@ int run_prep(rt_ctx* c) {
     return RT_OK;
 }
 
+int rank_lds_entries(const rt_ctx* c);
 DevScene scene_view(const rt_ctx* c) {
     DevScene s;
     s.tri_geo = c->geo.p; s.tri_nrm = c->nrm.p; s.nodes = c->nodes.p; s.roots = c->roots.p;
     s.mats = c->mats.p; s.spheres = c->spheres.p; s.rank_slot = c->rank_slot.p; s.slot_id = c->slot_id.p; s.tri_box = c->scene_is_sah ? c->tri_box.p : nullptr; s.n_meshes = c->n_meshes; s.n_spheres = c->n_spheres;
     s.stack_depth = c->stack_depth;
     s.tlas_root = c->tlas_root;
+    s.rank_lds = rank_lds_entries(c);
     return s;
 }
 
@@ -631,8 +633,14 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
 // only as many entries as keep RT_WAVES workgroups resident live in LDS; the rare deeper ones go
 // to `stack_ovf` in global memory (DEEP instantiations; a scene whose whole stack fits runs the
 // instantiation without that test).
+// rank -> slot entries k_trace keeps in LDS: the whole table of a small SAH scene with a root table (the reference
+// structure needs no table: its slots are in rank order)
+int rank_lds_entries(const rt_ctx* c) {
+    return (c->scene_is_sah && c->tlas_root < 0 && c->n_slots <= 2048) ? c->n_slots : 0;
+}
+
 size_t trace_lds_bytes(const rt_ctx* c, int cap, bool cull, bool sah) {
-    const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_meshes) + RT_PC_F4) * sizeof(float4);
+    const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : (2 + 5) * c->n_meshes) + (size_t)(rank_lds_entries(c) + 3) / 4 + RT_PC_F4) * sizeof(float4);   // roots, materials, rank table, arguments
     const size_t lq = RT_LQ_OF(sah);
     return fixed + ((size_t)cap + lq) * RT_BLOCK * 4 + (cull ? lq * RT_BLOCK * 2 : 0);
 }
