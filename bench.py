@@ -11,7 +11,9 @@ also folds them into the accumulator; scene and accumulator resident in HBM).  r
 closest-hit query (calculateRayCollision, shaders/raytracer.fs.glsl:518-641 of the reference),
 counted exactly in-kernel by a separate counting launch of the same deterministic work.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU), `--scaling`:
+N > 1: one rank per GPU.  Either launched by torch.distributed.run (the driver's way: RANK / WORLD_SIZE in the
+environment) or plainly as `python bench.py --gpus N`, in which case this process starts the N ranks itself through
+torch.distributed.run (before it imports torch or touches a GPU) and forwards rank 0's line and the exit code.  `--scaling`:
   weak   (default) every rank renders all PASSES of the frame with its own pass indices (rank r
          takes 1+r, 1+r+N, ...), i.e. PASSES*N spp in total, into a SUM accumulator;
   strong the frame's PASSES are split over the ranks (raytracer_amd.distributed.shard_passes):
@@ -97,10 +99,25 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))       # this process never imports torch nor loads librt_hip.so
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
+
+    if os.environ.get("RT_BENCH_LAUNCH_CHECK") == "1":
+        # CPU-only check of the launch plumbing (tests/test_distributed_cpu.py): rendezvous over gloo, one collective,
+        # rank 0's line - and out, before anything needs a GPU.  Not a measurement.
+        import torch
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "rank_sum": int(t.item()), "scaling": args.scaling,
+                              "steps": args.steps, "warmup": args.warmup}), flush=True)
+        dist.destroy_process_group()
+        return
 
     # The CPU baseline leg runs FIRST (rank 0, N = 1 only), before anything touches the GPU: the GPU
     # legs then form one contiguous stretch at the end of the process, which is what a sampler of GPU
@@ -224,13 +241,15 @@ def main() -> None:
     flop_launch = (FLOP_BOX * counts["box_tests"] + FLOP_TRI * counts["tri_tests"] + FLOP_HIT * counts["shaded_hits"]) / per_step
     # bytes the traversal touches, as if every fetch went to memory ...
     byte_launch = (BYTE_BOX * counts["box_tests"] + BYTE_TRI * counts["tri_tests"] + BYTE_HIT * counts["shaded_hits"]) / per_step
-    # ... and the streams that leave the L2: the accumulator, read and written once per pixel per launch, and the radiance of
-    # every sample, written to its wave's staging slot and read back once by the fold (12 + 12 B per (pixel, pass) - SURVEY.md
-    # 8(d)'s figure for passes that are accumulated one by one; the 75 MB of slots do not stay in 8 x 4 MB of L2)
+    # ... and the streams that leave the L2.  ALGORITHMIC (passes looped in-kernel): the accumulator, 12 B read +
+    # 12 B written per pixel per launch.  DESIGN OVERHEAD, not algorithmic: the radiance of every sample is parked in its wave's
+    # staging slot and read back once by the fold (12 + 12 B per (pixel, pass); the 75 MB of slots do not stay in 8 x 4 MB of L2) -
+    # the price of tracing the samples of a pixel on different lanes in any order while folding them in pass order.
+    accum_launch = 24.0 * WIDTH * HEIGHT
     stage_launch = 24.0 * WIDTH * HEIGHT * n_passes / per_step
-    hbm_launch = 24.0 * WIDTH * HEIGHT + stage_launch
+    hbm_launch = accum_launch + stage_launch
     achieved_tflops = flop_launch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    achieved_gbs = hbm_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    achieved_gbs = accum_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     cache_gbs = byte_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
     # HBM bytes per launch from the PMC passes of THIS command line (tools/prof_bench.sh; counters cannot be
@@ -250,30 +269,51 @@ def main() -> None:
 
     # for the record: the same frame on the reference's own BVH, culled and exact (rt_set_cull(0));
     # not the headline (the headline mode renders the identical image)
-    other = None
-    if not dist_on and not args.strict and not args.reference_structure and not args.no_other_modes and args.workload == "suzanne1080":
-        def timed2():
+    # These untimed legs run AFTER the timed region, each for about a second, so that the GPU stays busy for a few seconds at
+    # the end of the process (a sampler of GPU activity with a 5 s period otherwise misses a 1 s run).
+    other, band_only, audit = None, None, None
+    if not dist_on and not args.strict and not args.reference_structure and not args.no_other_modes and not REHEARSAL:
+        def timed2(min_s=1.0):
             step()
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            for _ in range(2):
+            n = 0
+            while n < 2 or time.perf_counter() - t1 < min_s:
                 step()
-            torch.cuda.synchronize(dev)
-            d = (time.perf_counter() - t1) / 2
-            return {"ms_per_step": round(d * 1e3, 3), "value": round(rays_step / d / 1e6, 2), "unit": "Mrays/s"}
+                torch.cuda.synchronize(dev)
+                n += 1
+            d = (time.perf_counter() - t1) / n
+            return {"ms_per_step": round(d * 1e3, 3), "value": round(rays_step / d / 1e6, 2), "unit": "Mrays/s", "steps": n}
 
-        ctx.set_accel(False)
-        ctx.load_scene(scene)
-        ctx.set_cull(True)
-        other = {"structure": "the reference's BVH as uploaded (rt_set_accel(RT_ACCEL_REFERENCE)), same rays, same image",
-                 "culled": timed2()}
-        ctx.set_cull(False)
-        other["exact_box_set"] = timed2()
+        # the fast mode with the weaker assumption: SAH structure + the distance band alone (rt_set_cull(ctx, RT_CULL_BAND))
+        ctx.set_cull(ffi.RT_CULL_BAND)
+        band_only = timed2()
+        band_only["mode"] = "SAH structure + culling rule (a) only (distance band 2^-10; DESIGN.md 5), same rays, same image"
+        # the culling audit of THIS frame, counted on the GPU by one counting launch of the exact mode (its winners are the
+        # reference's): queries whose winner's own bounding box either rule could skip (rt_stats_t.cull_audit)
+        ctx.set_cull(ffi.RT_CULL_OFF)
+        ctx.enable_stats(True)
+        ctx.reset_stats()
+        step()
+        torch.cuda.synchronize(dev)
+        ca = ctx.stats()["cull_audit"]
+        ctx.enable_stats(False)
+        audit = {"queries_won_by_a_triangle": int(ca[0]), "flagged_rule_a_band": int(ca[1]), "flagged_rule_b_behind": int(ca[2]),
+                 "note": "one exact-mode counting launch of this step on the GPU: queries whose winner's own box lies beyond the band (a) or is "
+                         "left before t = 5e-7 (b); 0 = no culling traversal of any structure over these triangles can lose a winner on this frame"}
+        if args.workload == "suzanne1080":
+            ctx.set_accel(False)
+            ctx.load_scene(scene)
+            ctx.set_cull(True)
+            other = {"structure": "the reference's BVH as uploaded (rt_set_accel(RT_ACCEL_REFERENCE)), same rays, same image",
+                     "culled": timed2()}
+            ctx.set_cull(False)
+            other["exact_box_set"] = timed2()
 
     if rank == 0:
         deep = info["stack_entries_lds"] < info["stack_entries"]
         kernel = "k_trace<STATS=false,CULL=%s,FIRST_HIT=false,SAH=%s,DEEP=%s>" % (
-            "false" if args.strict else "true", "false" if args.reference_structure else "true", "true" if deep else "false")
+            "0" if args.strict else "1", "false" if args.reference_structure else "true", "true" if deep else "false")
         hbm_frac = (traffic / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if (traffic and kern_ms > 0) else None
         out = {
             "metric": "Mrays/sec, Suzanne 1080p (rays = closest-hit queries, counted in-kernel)" if args.workload == "suzanne1080"
@@ -292,8 +332,10 @@ def main() -> None:
             "config": {
                 "workload": f"{wl['config']}: {wl['what']}, {WIDTH}x{HEIGHT}, {PASSES} spp ({PASSES} passes x {RPP} ray/px), "
                             f"{BOUNCES} bounces" + (", per GPU" if args.scaling == "weak" else ", whole job"),
-                "structure": "reference BVH" if args.reference_structure else "SAH over the same triangles, reference tie ranks (bit-identical image)",
-                "traversal": "strict (reference box set)" if args.strict else "distance-culled (bit-identical image)",
+                "structure": "reference BVH" if args.reference_structure else "SAH over the same triangles, reference tie ranks (exact by construction: DESIGN.md 5)",
+                "traversal": "strict (reference box set)" if args.strict else
+                             ("distance-culled, rules (a)+(b) (bit-identical to the oracle on this frame: tests/test_gpu_fullsize.py; "
+                              "cull_audit below is this frame's evidence)"),
                 "parallelism": "1 GPU, running mean" if not dist_on else
                                (f"spp-sharded x{world}, {args.scaling} scaling (rank r renders passes r+1, r+1+{world}, ...: {n_passes} on rank 0) "
                                 f"+ RCCL all-reduce of the {WIDTH*HEIGHT*12/1e6:.1f} MB sum"),
@@ -320,16 +362,23 @@ def main() -> None:
                 "hbm": {"achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(achieved_gbs / PEAK_HBM_GBS, 4),
                         "measured_frac": None if hbm_frac is None else round(hbm_frac, 4),
-                        "algorithmic_bytes_per_launch": int(hbm_launch),
-                        "staging_bytes_per_launch": int(stage_launch),
-                        "note": "algorithmic = accumulator (12 B read + 12 B written per pixel per launch) + staging (12 B written + 12 B "
-                                "read per sample in the waves' staging slots, 75 MB in all: they pass through the L2 to the Infinity Cache); "
-                                "measured_frac = roofline.traffic / launch time / peak; not the bound of this kernel"},
+                        "algorithmic_bytes_per_launch": int(accum_launch),
+                        "design_overhead_bytes_per_launch": int(stage_launch),
+                        "traffic_over_algorithmic": None if not traffic else round(traffic / accum_launch, 2),
+                        "traffic_over_algorithmic_plus_overhead": None if not traffic else round(traffic / hbm_launch, 3),
+                        "note": "algorithmic (SURVEY.md 8(d)) = the accumulator, 12 B read + 12 B written per pixel per launch; design overhead = "
+                                "the waves' staging slots (12 B written + 12 B read per sample, 75 MB in all: they pass through the L2 to the "
+                                "Infinity Cache) - the cost of folding passes in order inside the trace kernel instead of in a second kernel over "
+                                "a per-sample buffer; achieved/frac price the algorithmic bytes, measured_frac = roofline.traffic / launch time / "
+                                "peak; neither is the bound of this kernel"},
                 "cache": {"node_triangle_bytes_per_launch": int(byte_launch), "rate_GBps": round(cache_gbs, 1),
                           "note": "32 B/box test + 36 B/triangle test + 48 B/hit (SURVEY.md 8d), served by L1/L2 (Infinity Cache for subdiv4k)"},
             },
             "cpu_baseline": cpu,
             "reference_structure": other,
+            "sah_rule_a_only": band_only,
+            "cull_audit": audit,
+            "cull_audit_flagged": None if audit is None else audit["flagged_rule_a_band"] + audit["flagged_rule_b_behind"],
         }
         if REHEARSAL:
             out["rehearsal"] = "RT_BENCH_REHEARSAL=1: 160x90, 4 passes - not a measurement"
@@ -337,6 +386,23 @@ def main() -> None:
     ctx.close()
     if dist_on:
         dist.destroy_process_group()
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes through
+    torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) with this command line, let rank 0's JSON line flow
+    through on stdout, and return the launcher's exit code.  The parent touches no GPU and nothing is re-exec'd."""
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")             # (torchrun sets it anyway, with a warning)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(wl: dict, passes: int) -> dict:

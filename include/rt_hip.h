@@ -63,6 +63,11 @@ typedef struct rt_stats_t {
     /* wave scheduler statistics of counting launches (0 for the oracle): block executions and
      * the lanes active in them: {node_steps, node_lanes, tri_steps, tri_lanes, path_steps, path_lanes} */
     uint64_t sched[6];
+    /* culling audit of counting launches in the exact mode (rt_set_cull(ctx, RT_CULL_OFF); 0 otherwise and for
+     * the oracle, whose twin is rto_cull_audit): {closest-hit queries won by a triangle, of these: the winner's own
+     * bounding box lies beyond the distance band of rule (a), ... is left before t = 5e-7 (rule (b))}.  Zero in [1]
+     * and [2] = no culling traversal can lose a winner on the rays of those launches. */
+    uint64_t cull_audit[3];
 } rt_stats_t;
 
 /* What rt_set_scene built and how the most recent k_trace launch was laid out (for tests and
@@ -182,10 +187,22 @@ int rt_render(rt_ctx* ctx, uint32_t first_pass, uint32_t n_passes, uint32_t pass
  * is refused with RT_E_LIMIT if not even one workgroup fits.  Every context on a GPU shares that
  * GPU's array, which keeps the last call's contents: calls that overlap on one GPU (two contexts,
  * two streams) race; calls in stream order on one context do not.  Scene, camera, image size and
- * accumulator must have been set up before (those calls allocate). */
+ * accumulator must have been set up before (those calls allocate).  Pose updates must have been
+ * flushed: with an rt_update_mesh_pose / rt_update_mesh_transform pending the call returns
+ * RT_E_STATE (applying them copies from pageable host memory and synchronises the stream, neither
+ * of which is legal under stream capture) - call rt_prepare first, outside the capture.  A pending
+ * rt_set_materials alone is fine (one more kernel launch, nothing else). */
 #define RT_STATIC_SCRATCH_BYTES (64u << 20)
 int rt_render_static(rt_ctx* ctx, uint32_t first_pass, uint32_t n_passes, uint32_t pass_stride,
                      int rays_per_pixel, int max_bounces, int flags);
+
+/* replaces: the place where the reference runs its scene prep - update_triangles_to_csys, the BVH
+ * refit and the re-pack at the top of configure_buffers_and_uniforms (application.py:939-959),
+ * i.e. BEFORE the pass loop.  Applies every pending rt_update_mesh_pose / rt_update_mesh_transform
+ * / rt_set_materials on the device now (pose kernel, bottom-up refit, record re-pack; may copy from
+ * host memory and synchronise the stream).  rt_render / rt_first_hit / rt_read_* do this implicitly;
+ * rt_render_static refuses to (see above).  RT_E_STATE without a scene. */
+int rt_prepare(rt_ctx* ctx);
 
 /* replaces: the MAX_CYCLES uniform (application.py:132, 997): a pass whose index (frameNumber)
  * is larger leaves the image as it is (raytracer.fs.glsl:931-935) - rt_render skips it.
@@ -204,13 +221,19 @@ int rt_read_mean(rt_ctx* ctx, float* out_whc);
 /* tell the context how many passes an externally combined (all-reduced) SUM now holds */
 int rt_set_accum_passes(rt_ctx* ctx, uint64_t n_passes);
 
-/* Traversal mode.  0 (default) = STRICT: every box the reference would open is opened, so
- * results equal the oracle bit-for-bit.  1 = CULL: boxes wholly behind the ray origin or
- * wholly beyond the current closest hit (with a 2^-10 relative+absolute safety band) are
- * skipped; differs from STRICT only for rays whose triangle distance is off by more than
- * that band (grazing incidence, DESIGN.md "culling").  No reference counterpart (the
- * reference never culls, raytracer.fs.glsl:558-632). */
-int rt_set_cull(rt_ctx* ctx, int enable);
+/* Traversal mode.  RT_CULL_OFF (default) = STRICT: every box the reference would open is opened,
+ * so results equal the oracle bit-for-bit.  RT_CULL_ON: boxes (a) wholly beyond the current closest
+ * hit (with a 2^-10 relative+absolute safety band) or (b) left by the ray before t = 5e-7 are
+ * skipped.  RT_CULL_BAND: rule (a) alone - it can drop a hit only if the triangle's computed distance
+ * is short of its own box by more than the band, i.e. a rounding error of the plane distance beyond
+ * 2^-10 (1 + t): rays within ~0.2 degrees of a surface's plane at the coordinates of the shipped
+ * scenes (bound in DESIGN.md 5); rule (b) has a real, found, one-ulp failure case (ibid.).
+ * RT_E_ARG for any other value.  No reference counterpart (the reference never culls,
+ * raytracer.fs.glsl:558-632).  Oracle: accepted and ignored. */
+#define RT_CULL_OFF 0
+#define RT_CULL_ON 1
+#define RT_CULL_BAND 2
+int rt_set_cull(rt_ctx* ctx, int mode);
 
 /* counters: enable => launches use the counting kernel variant (slower; not for timing) */
 int rt_enable_stats(rt_ctx* ctx, int enable);

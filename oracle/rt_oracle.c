@@ -896,6 +896,8 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
 int rt_render_static(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int rpp, int maxBounces, int flags) {
     return rt_render(c, first, n_passes, stride, rpp, maxBounces, flags);
 }
+/* the oracle applies poses when they are set: nothing is ever pending */
+int rt_prepare(rt_ctx* c) { if (!c) return RT_E_ARG; if (!c->have_scene) FAIL(c, RT_E_STATE, "no scene"); return RT_OK; }
 int rt_set_max_cycles(rt_ctx* c, uint32_t m) { if (!c) return RT_E_ARG; c->max_cycles = m; return RT_OK; }
 
 int rt_first_hit(rt_ctx* c, uint32_t pass, int32_t* ids, float* ts) {

@@ -152,11 +152,13 @@ __device__ __forceinline__ bool box_test_finite(v3 o, v3 inv, float4 lo, float4 
     return tmin <= tmax;
 }
 
-// true when the culling band allows skipping a box with interval [tmin,tmax]; NaN never culls
-template <bool CULL>
+// true when the culling rules allow skipping a box with interval [tmin,tmax]; NaN never culls.
+// CULL: RT_CULL_OFF (0) no rule, RT_CULL_ON (1) both rules, RT_CULL_BAND (2) the distance band alone (rule (a): the
+// only way it can drop a hit is a triangle distance that is off by more than the band)
+template <int CULL>
 __device__ __forceinline__ bool culled(float tmin, float tmax, float best_t) {
     if (!CULL) return false;
-    return (tmax < RT_CULL_BEHIND) || (tmin > fma_(best_t, RT_CULL_REL, best_t) + RT_CULL_ABS);
+    return (CULL == 1 && tmax < RT_CULL_BEHIND) || (tmin > fma_(best_t, RT_CULL_REL, best_t) + RT_CULL_ABS);
 }
 
 // SAH structure only.  Its boxes are not the reference's, so their slab tests are made
@@ -292,7 +294,7 @@ struct Trav {
 // root box the ray's line touches.  A leaf root is tested as the reference does (:586); for an
 // interior root the test is an exact shortcut: child boxes nest inside it and float
 // subtract/multiply are monotonic, so no child test could pass when the root test fails.
-template <bool STATS, bool CULL, bool FINITE>
+template <bool STATS, int CULL, bool FINITE>
 __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn, v3 org, v3 inv, float best_t, bool sah, Counters& cnt, int& nearest) {
     uint32_t mask = 0;
     float near_t = __builtin_inff();      // (an entry distance of +inf or NaN leaves `nearest` unset: the order is a heuristic only)
@@ -330,7 +332,7 @@ __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn
     return mask;
 }
 
-template <bool STATS, bool CULL>
+template <bool STATS, int CULL>
 __device__ __forceinline__ uint32_t root_mask(int jn, const float4* s_roots, v3 org, v3 inv, float best_t, bool sah, Counters& cnt, int& nearest) {
     // wave-uniform choice of the slab-test form (see box_test_finite)
     const bool all_finite = __ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0;
@@ -442,7 +444,7 @@ __device__ __forceinline__ void fold_job(const TraceArgs* Pp, const WaveJobs* wj
     }
 }
 
-template <bool STATS, bool CULL, bool FIRST_HIT, bool SAH, bool DEEP>
+template <bool STATS, int CULL, bool FIRST_HIT, bool SAH, bool DEEP>
 __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) {
     const DevScene& S = a.scene;
     // ---- LDS: mesh root table (2 float4 per mesh), then the per-lane columns
@@ -487,6 +489,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     const int lane = threadIdx.x & 63;
     Counters cnt = {0, 0, 0, 0};
     SchedStats sch = {0, 0, 0, 0, 0, 0};
+    struct { unsigned long long n, band, behind; } aud = {0, 0, 0};   // culling audit (STATS builds of the exact mode)
 
     // ---- wave-uniform work cursor ---------------------------------------------------------
     // Work is handed out in jobs = one small tile of pixels with all passes of the launch (~512 samples),
@@ -593,8 +596,13 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         m_h2 &= lane_mask(ref2 != RT_NONE);
                         if (CULL) {                                 // culled(): NaN never culls
                             const float beyond = fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS;
-                            m_h1 &= ~(lane_mask(t1b < RT_CULL_BEHIND) | lane_mask(t1a > beyond));
-                            m_h2 &= ~(lane_mask(t2b < RT_CULL_BEHIND) | lane_mask(t2a > beyond));
+                            if (CULL == 1) {
+                                m_h1 &= ~(lane_mask(t1b < RT_CULL_BEHIND) | lane_mask(t1a > beyond));
+                                m_h2 &= ~(lane_mask(t2b < RT_CULL_BEHIND) | lane_mask(t2a > beyond));
+                            } else {                                // the band alone (rt_set_cull(ctx, RT_CULL_BAND))
+                                m_h1 &= ~lane_mask(t1a > beyond);
+                                m_h2 &= ~lane_mask(t2a > beyond);
+                            }
                         }
                         if (STATS) cnt.box += (ref1 != RT_NONE) + (ref2 != RT_NONE);
                         const uint64_t m_sn = lane_mask(t2a < t1a);   // far child first, so that the near one is taken up first
@@ -693,6 +701,9 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
         if (__ballot(mode == M_PATH) == 0) break;                  // every lane is M_DONE (a lane in M_WAIT implies samples in flight, i.e. lanes that traverse)
 
         // =============== path phase: shade the finished query, start the next one ===============
+#ifdef RT_PRIO_PATH   // A/B only (profiles/r03_k_trace_isa.txt): wave priority of the path block / of the traversal loop
+        __builtin_amdgcn_s_setprio(RT_PRIO_PATH);
+#endif
         if (STATS) { sch.path_steps++; sch.path_lanes += __popcll(__ballot(mode == M_PATH)); }
         bool need = mode == M_WAIT, start = false, redo = false, completed = false;
         if (mode == M_PATH) {
@@ -751,6 +762,25 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         hit_mat = __float_as_int(na.w);
                     }
                     if (STATS) cnt.hits += !redo;
+                    if (STATS && !CULL && !redo && tv.best_rank >= 0) {
+                        // Culling audit (counting launches of the exact mode only; the oracle's rto_cull_audit): could a culling
+                        // rule skip the WINNER's own bounding box, with the winner's own distance as the best in hand?  That box
+                        // lies inside every box any structure over the same triangles puts the triangle in, and float
+                        // subtract / multiply are monotonic, so its interval lies inside theirs: no flagged query means no
+                        // culling traversal of either structure can lose the reference's winner on this launch's rays.
+                        const int slot = SAH ? rank_slot[tv.best_rank] : tv.best_rank;
+                        const float4* g = S.tri_geo + 4 * (size_t)slot;
+                        const float4 a0 = g[0], a1 = g[1], a2 = g[2];
+                        const float4 lo = make_float4(__builtin_fminf(a0.x, __builtin_fminf(a1.x, a2.x)), __builtin_fminf(a0.y, __builtin_fminf(a1.y, a2.y)),
+                                                      __builtin_fminf(a0.z, __builtin_fminf(a1.z, a2.z)), 0.f);
+                        const float4 hi = make_float4(__builtin_fmaxf(a0.x, __builtin_fmaxf(a1.x, a2.x)), __builtin_fmaxf(a0.y, __builtin_fmaxf(a1.y, a2.y)),
+                                                      __builtin_fmaxf(a0.z, __builtin_fmaxf(a1.z, a2.z)), 0.f);
+                        float own_lo, own_hi;
+                        box_test(org, inv, lo, hi, own_lo, own_hi);      // the ladder's interval, hit or not
+                        aud.n++;
+                        aud.band += own_lo > fma_(best_t, RT_CULL_REL, best_t) + RT_CULL_ABS;
+                        aud.behind += own_hi < RT_CULL_BEHIND;
+                    }
                     const MatDev* m = hit_mat < 256 ? &s_mats[hit_mat] : &PS.spheres[hit_mat - 256].material;
                     const float alpha = m->color[3];
                     bool ended = false, passthrough = redo;   // a query to be repeated changes nothing here
@@ -969,6 +999,9 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 mode = M_TRAV;
             }
         }
+#ifdef RT_PRIO_PATH
+        __builtin_amdgcn_s_setprio(RT_PRIO_TRAV);
+#endif
         // The wave is converged here: take the two lane masks anew, for the queries that have just started and (to the
         // same values: node work remains <=> a record in hand, a deferred one or a root left) for those still in flight.
         // A lane without a query keeps the 1/d of its last one; its bit in m_nonfinite is never looked at.
@@ -989,6 +1022,15 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             unsigned long long x = v[q];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
             if ((threadIdx.x & 63) == 0 && x) atomicAdd(a.counters + q, x);
+        }
+        if (!CULL && !FIRST_HIT) {
+            unsigned long long u[3] = {aud.n, aud.band, aud.behind};
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                unsigned long long x = u[q];
+                for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+                if ((threadIdx.x & 63) == 0 && x) atomicAdd(a.counters + 10 + q, x);
+            }
         }
         if ((threadIdx.x & 63) == 0) {
             const unsigned long long w[6] = {sch.node_steps, sch.node_lanes, sch.tri_steps, sch.tri_lanes, sch.path_steps, sch.path_lanes};

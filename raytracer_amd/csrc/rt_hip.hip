@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const 
 #ifndef RT_WAVES
 #define RT_WAVES 5
 #endif
-template <bool STATS, bool CULL, bool FIRST_HIT, bool SAH, bool DEEP>
+template <bool STATS, int CULL, bool FIRST_HIT, bool SAH, bool DEEP>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES) void k_trace(TraceArgs a) {
     extern __shared__ float4 s_mem[];
     trace_pixels<STATS, CULL, FIRST_HIT, SAH, DEEP>(a, s_mem);
@@ -244,9 +244,11 @@ struct DevBuf {
     size_t n = 0;
     hipError_t alloc(size_t count) {
         release();
-        n = count;
         if (!count) return hipSuccess;
-        return hipMalloc((void**)&p, count * sizeof(T));
+        const hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return e; }   // n stays 0: "capacity < need" checks must not pass with a null buffer
+        n = count;
+        return hipSuccess;
     }
     void release() {
         if (p) (void)hipFree(p);
@@ -427,7 +429,7 @@ struct rt_ctx {
     int tlas_root = -1;                   // record of the top-level tree's root (scenes with > 32 meshes), else -1
     bool have_scene = false, have_cam = false, prep_pending = false;
     bool flags_pending = false;           // materials changed since the triangle flag words were written
-    bool cull = false;                    // conservative distance culling (rt_set_cull)
+    int cull = RT_CULL_OFF;               // distance culling (rt_set_cull): RT_CULL_OFF / RT_CULL_ON / RT_CULL_BAND
     int node_bias = 0;
     int burst8 = -1;                      // RT_BURST8; -1 = measured default (4 of 8 lanes, SAH scenes: 3 of 8)
     uint32_t job_samples = RT_JOB_SAMPLES;   // RT_JOB_SAMPLES: samples of a job (measurements)
@@ -645,7 +647,7 @@ size_t trace_lds_bytes(const rt_ctx* c, int cap, bool cull, bool sah) {
     return fixed + ((size_t)cap + lq) * RT_BLOCK * 4 + (cull ? lq * RT_BLOCK * 2 : 0);
 }
 
-template <bool STATS, bool CULL, bool FIRST, bool SAH, bool DEEP>
+template <bool STATS, int CULL, bool FIRST, bool SAH, bool DEEP>
 int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     if (c->blocks_per_cu[key] <= 0) {
         int nb = 0, nb_best = 0;
@@ -722,7 +724,7 @@ int lds_stack_entries(const rt_ctx* c) {
     return std::max(RT_MIN_STACK_LDS, std::min(c->stack_depth, fit));
 }
 
-template <bool STATS, bool CULL, bool FIRST>
+template <bool STATS, int CULL, bool FIRST>
 int launch_accel(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     const bool deep = cap < c->stack_depth;
     if (c->scene_is_sah) return deep ? launch_one<STATS, CULL, FIRST, true, true>(c, a, key, cap) : launch_one<STATS, CULL, FIRST, true, false>(c, a, key, cap);
@@ -730,19 +732,24 @@ int launch_accel(rt_ctx* c, const TraceArgs& a, int key, int cap) {
 }
 
 int launch_trace(rt_ctx* c, const TraceArgs& a, bool first_hit) {
-    // the instantiation is fixed by (stats, cull, first hit) and, per scene, by (structure, deep):
-    // 8 cache slots for the occupancy of the scene in place
-    const int key = (c->stats_on ? 4 : 0) | (c->cull ? 2 : 0) | (first_hit ? 1 : 0);
+    // the instantiation is fixed by (stats, cull mode, first hit) and, per scene, by (structure, deep):
+    // 12 cache slots (of 16) for the occupancy of the scene in place
+    const int key = (c->stats_on ? 8 : 0) | (c->cull << 1) | (first_hit ? 1 : 0);
     const int cap = lds_stack_entries(c);
     switch (key) {
-    case 0: return launch_accel<false, false, false>(c, a, key, cap);
-    case 1: return launch_accel<false, false, true>(c, a, key, cap);
-    case 2: return launch_accel<false, true, false>(c, a, key, cap);
-    case 3: return launch_accel<false, true, true>(c, a, key, cap);
-    case 4: return launch_accel<true, false, false>(c, a, key, cap);
-    case 5: return launch_accel<true, false, true>(c, a, key, cap);
-    case 6: return launch_accel<true, true, false>(c, a, key, cap);
-    default: return launch_accel<true, true, true>(c, a, key, cap);
+    case 0: return launch_accel<false, 0, false>(c, a, key, cap);
+    case 1: return launch_accel<false, 0, true>(c, a, key, cap);
+    case 2: return launch_accel<false, 1, false>(c, a, key, cap);
+    case 3: return launch_accel<false, 1, true>(c, a, key, cap);
+    case 4: return launch_accel<false, 2, false>(c, a, key, cap);
+    case 5: return launch_accel<false, 2, true>(c, a, key, cap);
+    case 8: return launch_accel<true, 0, false>(c, a, key, cap);
+    case 9: return launch_accel<true, 0, true>(c, a, key, cap);
+    case 10: return launch_accel<true, 1, false>(c, a, key, cap);
+    case 11: return launch_accel<true, 1, true>(c, a, key, cap);
+    case 12: return launch_accel<true, 2, false>(c, a, key, cap);
+    case 13: return launch_accel<true, 2, true>(c, a, key, cap);
+    default: return fail(c, RT_E_STATE, "no k_trace instantiation for key %d", key);
     }
 }
 
@@ -1295,6 +1302,12 @@ static int render_impl(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t st
     if (first > c->max_cycles) n_passes = 0;
     else n_passes = (uint32_t)std::min<uint64_t>(n_passes, ((uint64_t)c->max_cycles - first) / stride + 1);
     HIPCK(c, hipSetDevice(c->device));
+    // rt_render_static allocates nothing and must be legal under stream capture: a pending pose update would make run_prep
+    // copy from pageable memory and synchronise the stream (and may rebuild the top-level tree), so it is refused here -
+    // the caller flushes with rt_prepare (or any rt_render / rt_first_hit) first.  A pending materials-only update is one
+    // kernel launch (k_tri_flags; its copy was queued from pinned memory by rt_set_materials) and goes through.
+    if (use_static && c->prep_pending)
+        return fail(c, RT_E_STATE, "rt_render_static: pose updates are pending; call rt_prepare first (it may synchronise, rt_render_static must not)");
     if ((rc = run_prep(c))) return rc;
     TraceArgs a;
     fill_args(c, a);
@@ -1340,6 +1353,13 @@ int rt_render(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int
 
 int rt_render_static(rt_ctx* c, uint32_t first, uint32_t n_passes, uint32_t stride, int rpp, int max_bounces, int flags) {
     return render_impl(c, first, n_passes, stride, rpp, max_bounces, flags, true);
+}
+
+int rt_prepare(rt_ctx* c) {
+    if (!c) return RT_E_ARG;
+    if (!c->have_scene) return fail(c, RT_E_STATE, "no scene");
+    HIPCK(c, hipSetDevice(c->device));
+    return run_prep(c);
 }
 
 int rt_set_max_cycles(rt_ctx* c, uint32_t max_cycles) {
@@ -1397,7 +1417,15 @@ int rt_read_accum(rt_ctx* c, float* out, uint64_t* n_out) {
     if (!c->accum) return fail(c, RT_E_STATE, "no image size");
     HIPCK(c, hipSetDevice(c->device));
     HIPCK(c, hipMemcpyAsync(out, c->accum, (size_t)c->cam.width * c->cam.height * 12, hipMemcpyDeviceToHost, c->stream));
+    // k_trace's end-of-kernel check (a job slot still in use = radiance that never reached the accumulator): an image with
+    // missing pixels must not be handed out as RT_OK.  Reported once, then cleared.
+    unsigned long long unfolded = 0;
+    HIPCK(c, hipMemcpyAsync(&unfolded, c->counters.p + 15, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    if (unfolded) {
+        (void)hipMemsetAsync(c->counters.p + 15, 0, 8, c->stream);
+        return fail(c, RT_E_DEVICE, "internal error: %llu jobs were not folded into the accumulator", unfolded);
+    }
     if (n_out) *n_out = c->n_accum;
     return RT_OK;
 }
@@ -1420,9 +1448,10 @@ int rt_set_accel(rt_ctx* c, int accel) {
     return RT_OK;
 }
 
-int rt_set_cull(rt_ctx* c, int enable) {
+int rt_set_cull(rt_ctx* c, int mode) {
     if (!c) return RT_E_ARG;
-    c->cull = enable != 0;
+    if (mode != RT_CULL_OFF && mode != RT_CULL_ON && mode != RT_CULL_BAND) return fail(c, RT_E_ARG, "unknown culling mode %d", mode);
+    c->cull = mode;
     return RT_OK;
 }
 
@@ -1466,9 +1495,13 @@ int rt_get_stats(rt_ctx* c, rt_stats_t* o) {
     unsigned long long h[16];
     HIPCK(c, hipMemcpyAsync(h, c->counters.p, 128, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    if (h[15]) return fail(c, RT_E_DEVICE, "internal error: %llu jobs were not folded into the accumulator", h[15]);
+    if (h[15]) {                                   // reported once (here or by rt_read_accum), then cleared
+        (void)hipMemsetAsync(c->counters.p + 15, 0, 8, c->stream);
+        return fail(c, RT_E_DEVICE, "internal error: %llu jobs were not folded into the accumulator", h[15]);
+    }
     c->st.rays = h[0]; c->st.box_tests = h[1]; c->st.tri_tests = h[2]; c->st.shaded_hits = h[3];
     for (int q = 0; q < 6; q++) c->st.sched[q] = h[4 + q];
+    for (int q = 0; q < 3; q++) c->st.cull_audit[q] = h[10 + q];
     *o = c->st;
     return RT_OK;
 }

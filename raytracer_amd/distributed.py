@@ -207,7 +207,9 @@ class ShardedAnimation:
         if img is not None:
             t.copy_(torch.from_numpy(np.ascontiguousarray(img)))
         bufs = [torch.empty_like(t) for _ in range(self.world)] if self.rank == 0 else None
-        self.dist.gather(t, bufs, dst=0, group=self.group)
+        # `dst` is a GLOBAL rank while self.rank is the rank inside `group`: they differ for a sub-group without global rank 0
+        dst = 0 if self.group is None else self.dist.get_global_rank(self.group, 0)
+        self.dist.gather(t, bufs, dst=dst, group=self.group)
         return [b.cpu().numpy() for b in bufs] if self.rank == 0 else None
 
     def close(self) -> None:

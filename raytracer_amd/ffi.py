@@ -15,6 +15,7 @@ HIP_LIB = Path(__file__).resolve().parent / "librt_hip.so"
 
 RT_ACCUM_MEAN = 0
 RT_ACCUM_SUM = 1
+RT_CULL_OFF, RT_CULL_ON, RT_CULL_BAND = 0, 1, 2
 
 
 class RtStats(C.Structure):
@@ -27,11 +28,13 @@ class RtStats(C.Structure):
         ("kernel_ms", C.c_double),
         ("launches", C.c_uint64),
         ("sched", C.c_uint64 * 6),
+        ("cull_audit", C.c_uint64 * 3),
     ]
 
     def as_dict(self) -> dict:
         d = {k: getattr(self, k) for k, _ in self._fields_}
         d["sched"] = list(self.sched)
+        d["cull_audit"] = list(self.cull_audit)
         return d
 
 
@@ -69,6 +72,7 @@ _SIGNATURES = {
     "rt_bind_accum": (C.c_int, [_vp, _vp]),
     "rt_render": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]),
     "rt_render_static": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]),
+    "rt_prepare": (C.c_int, [_vp]),
     "rt_set_max_cycles": (C.c_int, [_vp, C.c_uint32]),
     "rt_first_hit": (C.c_int, [_vp, C.c_uint32, _vp, _vp]),
     "rt_read_accum": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64)]),
@@ -252,6 +256,10 @@ class RtContext:
             "rt_render_static",
         )
 
+    def prepare(self) -> None:
+        """Apply pending pose / material updates on the device now (rt_render does it implicitly, rt_render_static refuses to)."""
+        self._ck(self.lib.dll.rt_prepare(self._h), "rt_prepare")
+
     def set_max_cycles(self, max_cycles: int) -> None:
         """MAX_CYCLES uniform (application.py:997): passes with a larger index leave the image unchanged."""
         self._ck(self.lib.dll.rt_set_max_cycles(self._h, int(max_cycles) & 0xFFFFFFFF), "rt_set_max_cycles")
@@ -278,8 +286,9 @@ class RtContext:
         """Structure the NEXT set_scene builds: False = the reference's BVH (parity), True = SAH."""
         self._ck(self.lib.dll.rt_set_accel(self._h, 1 if sah else 0), "rt_set_accel")
 
-    def set_cull(self, on: bool) -> None:
-        self._ck(self.lib.dll.rt_set_cull(self._h, int(on)), "rt_set_cull")
+    def set_cull(self, mode) -> None:
+        """False / 0 = exact box set, True / 1 = both culling rules, 2 (RT_CULL_BAND) = the distance band alone."""
+        self._ck(self.lib.dll.rt_set_cull(self._h, int(mode)), "rt_set_cull")
 
     def enable_stats(self, on: bool = True) -> None:
         self._ck(self.lib.dll.rt_enable_stats(self._h, int(on)), "rt_enable_stats")

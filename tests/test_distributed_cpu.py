@@ -137,3 +137,48 @@ def test_frame_sharding_world2_gloo(tmp_path, oracle_lib):
     c = make_ctx(oracle_lib, build_suzanne(43), AW, AH)
     c.render(1, APASSES, 1, 1, ABOUNCES, 0)
     assert np.array_equal(c.read_mean().view(np.uint32), ref[43].view(np.uint32))
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_launches_itself_for_n_gpus(launcher):
+    """`python bench.py --gpus 2` with no launcher starts its two ranks itself (torch.distributed.run children of a parent
+    that never touches a GPU); the driver's shape - torch.distributed.run around bench.py - keeps working.  CPU-only: the
+    ranks meet over gloo, run one collective and print rank 0's line (RT_BENCH_LAUNCH_CHECK=1) before the GPU is needed;
+    the full two-rank step runs on the GPU box (tests/test_gpu_rccl_single_rank.py)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["RT_BENCH_LAUNCH_CHECK"] = "1"
+    args = [str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling", "strong"]
+    if launcher == "self":
+        cmd = [sys.executable, *args]
+    else:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), *args]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["launch_check"] and d["n_gpus"] == 2 and d["rank_sum"] == 3 and d["steps"] == 3 and d["scaling"] == "strong"
+
+
+def test_bench_self_launch_forwards_a_failing_exit_code():
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["RT_BENCH_LAUNCH_CHECK"] = "1"
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--workload", "no-such-workload"], env=env,
+                       capture_output=True, text=True, timeout=240, cwd=root)
+    assert r.returncode != 0

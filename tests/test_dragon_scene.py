@@ -59,3 +59,33 @@ def test_dragon_scene_bit_exact(oracle_lib, hip_lib, dragon):
     assert np.array_equal(b.view(np.uint32), c.view(np.uint32))
     print(f"dragon scene: box tests/ray strict {sg['box_tests']/sg['rays']:.1f} -> culled {sc_['box_tests']/sc_['rays']:.1f}; "
           f"triangle tests/ray {sg['tri_tests']/sg['rays']:.1f} -> {sc_['tri_tests']/sc_['rays']:.1f}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+def test_dragon_scene_sah_culled_vs_oracle(oracle_lib, hip_lib, dragon, mode):
+    """The mode `bench.py --workload dragon` times: SAH per-mesh trees under the top-level tree, distance culling, 8
+    bounces, node stack partly in global memory - against the ORACLE (the reference's flat loop over 192 mesh roots,
+    raytracer.fs.glsl:546-552).  mode 2 = the distance band alone."""
+    w, h = 256, 144
+    co = make_ctx(oracle_lib, dragon, w, h)
+    io, to = co.first_hit(1)
+    co.render(1, 4, 1, 1, 8, 0)
+    a = co.read_mean()
+    co.close()
+    cg = hip_lib.create()
+    cg.set_accel(True)
+    cg.load_scene(dragon)
+    cg.load_camera(dragon.cam)
+    cg.resize(w, h)
+    cg.set_cull(mode)
+    ig, tg = cg.first_hit(1)
+    cg.render(1, 4, 1, 1, 8, 0)
+    b = cg.read_mean()
+    info = cg.info()
+    cg.close()
+    assert info["accel"] == 1 and info["top_level_tree"] == 1
+    assert info["stack_entries_lds"] < info["stack_entries"], info
+    assert a.max() > 0 and len(np.unique(io[io >= 0])) > 1000
+    assert np.array_equal(io, ig) and np.array_equal(to.view(np.uint32), tg.view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).any(axis=2).sum()} pixels differ"

@@ -33,7 +33,15 @@ def test_bench_line_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["traffic"] is None or r["traffic"] >= r["hbm"]["algorithmic_bytes_per_launch"]
+    h = r["hbm"]
+    # algorithmic = 24 B per pixel per launch (accumulator); the staging stream is design overhead, named as such
+    assert h["algorithmic_bytes_per_launch"] == 24 * 1920 * 1080 and h["design_overhead_bytes_per_launch"] == 24 * 1920 * 1080 * 64
+    assert r["traffic"] is None or r["traffic"] >= h["algorithmic_bytes_per_launch"]
+    assert r["traffic"] is None or abs(h["traffic_over_algorithmic"] - r["traffic"] / h["algorithmic_bytes_per_launch"]) < 0.01
+    # the headline's evidence for THIS frame, and the fast mode with the weaker assumption, ride on the same line
+    assert d["cull_audit_flagged"] == 0 and d["cull_audit"]["queries_won_by_a_triangle"] > 5e8
+    assert d["sah_rule_a_only"]["ms_per_step"] > 0.9 * d["ms_per_step"]
+    assert d["reference_structure"]["culled"]["ms_per_step"] > d["ms_per_step"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

@@ -211,3 +211,73 @@ def test_near_axis_rays_culling_differs_only_where_the_audit_says(oracle_lib, hi
             ic, tc, c, _ = _render(hip_lib, near_axis_scene(seed, 1e-6, eps), w, h, True, 2, 2, 6, sah=sah)
             differing = int((a.view(np.uint32) != c.view(np.uint32)).any(axis=2).sum())
             assert differing <= flagged, f"seed {seed} eps {eps} sah={sah}: {differing} pixels differ, the audit flags {flagged} queries"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_gpu_cull_audit_equals_the_oracles_and_band_only_mode(oracle_lib, hip_lib, seed):
+    """The culling audit that bench.py reports with every line (rt_stats_t.cull_audit, counted by the exact mode's
+    counting launch on the GPU) is the oracle's rto_cull_audit: same queries, same own-box flags for both rules, on the
+    adversarial near-axis scenes where flagged queries do exist.  And rt_set_cull(ctx, RT_CULL_BAND) - rule (a) alone -
+    may differ from the oracle in at most the queries rule (a) flags (none here: it stays bit-equal)."""
+    import ctypes
+
+    from conftest import ORACLE_SO
+    from raytracer_amd import ffi
+    from test_oracle_cull_audit import near_axis_scene
+
+    audit = ctypes.CDLL(str(ORACLE_SO)).rto_cull_audit
+    out = (ctypes.c_ulonglong * 5)()
+    total_flagged = 0
+    for eps, (w, h) in ((1e-6, (1, 129)), (-3e-7, (129, 1))):
+        sc = near_axis_scene(seed, 1e-6, eps)
+        co = oracle_lib.create()
+        co.load_scene(sc)
+        co.load_camera(sc.cam)
+        co.resize(w, h)
+        audit(ctypes.c_int(1), None)
+        co.render(1, 2, 1, 2, 6, 0)
+        audit(ctypes.c_int(0), out)
+        ref = co.read_mean()
+        co.close()
+        for sah in (False, True):
+            cg = hip_lib.create()
+            cg.set_accel(sah)
+            cg.load_scene(sc)
+            cg.load_camera(sc.cam)
+            cg.resize(w, h)
+            cg.set_cull(ffi.RT_CULL_OFF)
+            cg.enable_stats(True)
+            cg.render(1, 2, 1, 2, 6, 0)
+            st = cg.stats()
+            assert np.array_equal(ref.view(np.uint32), cg.read_mean().view(np.uint32))
+            assert st["cull_audit"] == [int(out[0]), int(out[3]), int(out[4])], f"seed {seed} eps {eps} sah={sah}: {st['cull_audit']} vs {list(out)}"
+            # rule (a) alone: differs in at most the queries its own audit flags
+            cg.enable_stats(False)
+            cg.set_cull(ffi.RT_CULL_BAND)
+            cg.reset_accum()
+            cg.render(1, 2, 1, 2, 6, 0)
+            band = cg.read_mean()
+            differing = int((ref.view(np.uint32) != band.view(np.uint32)).any(axis=2).sum())
+            assert differing <= int(out[3]), f"seed {seed} eps {eps} sah={sah}: band-only differs in {differing} pixels, rule (a) flags {int(out[3])}"
+            # a culled counting launch reports no audit (its winner is not the reference's by construction)
+            cg.set_cull(ffi.RT_CULL_ON)
+            cg.enable_stats(True)
+            cg.reset_stats()
+            cg.reset_accum()
+            cg.render(1, 2, 1, 2, 6, 0)
+            assert cg.stats()["cull_audit"] == [0, 0, 0]
+            cg.close()
+        total_flagged += int(out[3]) + int(out[4])
+    print(f"seed {seed}: own-box audit flags {total_flagged} queries")
+
+
+@pytest.mark.gpu
+def test_set_cull_rejects_unknown_modes(hip_lib):
+    from raytracer_amd.ffi import RtError
+
+    c = hip_lib.create()
+    with pytest.raises(RtError) as e:
+        c.set_cull(3)
+    assert e.value.code == -1
+    c.close()

@@ -38,6 +38,25 @@ def test_bench_takes_the_rccl_path_with_one_rank():
     assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL all-reduce" in line["config"]["parallelism"]
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bench_self_launch_two_ranks_share_the_card():
+    """`python bench.py --gpus 2` with no launcher, on the one GPU of the box: the parent starts both ranks itself; they share
+    the card (gloo between them, tiny frames, turns: RT_BENCH_REHEARSAL), walk the whole N = 2 step - sharded passes, SUM
+    accumulation, all-reduce, max-over-ranks timing - and rank 0's ONE line comes back with n_gpus == 2.  Not a measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RT_BENCH_REHEARSAL="1", RT_BENCH_BACKEND="gloo", RT_BENCH_WATCHDOG="200", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for scaling in ("weak", "strong"):
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scaling", scaling],
+                           env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0 and "rehearsal" in line
+        assert "spp-sharded x2" in line["config"]["parallelism"]
+
+
 _SHARDED = r"""
 import sys
 import numpy as np, torch, torch.distributed as dist

@@ -78,3 +78,36 @@ def test_million_triangles(oracle_lib, hip_lib):
     s.reset_accum()
     s.render(1, 2, 1, 1, 4, 0)
     assert np.array_equal(m1.view(np.uint32), s.read_mean().view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
+def test_million_triangles_sah_culled_deep_vs_oracle(oracle_lib, hip_lib, mode):
+    """The mode `bench.py --workload subdiv4k` times: 991 316 triangles on the SAH structure with distance culling, node
+    stack deeper than its LDS part (DEEP instantiation, the scheduler's refill_below 24 branch for scenes that do not fit
+    the L2) - against the ORACLE (raytracer.fs.glsl:518-641 restated), not only against the exact mode.  mode 2 = the
+    distance band alone (rt_set_cull(ctx, RT_CULL_BAND))."""
+    sc = _scene(5, hip_lib, frame=7)
+    W, H = 480, 270
+    co = make_ctx(oracle_lib, sc, W, H)
+    io, to = co.first_hit(1)
+    co.render(1, 2, 1, 1, 4, 0)
+    a = co.read_mean()
+    co.close()
+    cg = hip_lib.create()
+    cg.set_accel(True)
+    cg.load_scene(sc)
+    cg.load_camera(sc.cam)
+    cg.resize(W, H)
+    cg.set_cull(mode)
+    ig, tg = cg.first_hit(1)
+    cg.render(1, 2, 1, 1, 4, 0)
+    b = cg.read_mean()
+    info = cg.info()
+    cg.close()
+    assert info["accel"] == 1 and info["n_slots"] > 100000
+    assert info["stack_entries_lds"] < info["stack_entries"], info           # DEEP: entries beyond LDS go to global memory
+    assert a.max() > 0 and len(np.unique(io)) > 10000
+    assert np.array_equal(io, ig), f"{(io != ig).sum()} first-hit ids differ"
+    assert np.array_equal(to.view(np.uint32), tg.view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{(a != b).any(axis=2).sum()} pixels differ"
