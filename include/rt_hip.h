@@ -82,7 +82,8 @@ typedef struct rt_info_t {
     int32_t lds_bytes;          /* dynamic LDS per workgroup of that launch                                */
     int32_t workgroups_per_cu;  /* resident workgroups per CU of that launch                               */
     int32_t top_level_rebuilds; /* times the top-level tree was rebuilt from posed boxes                   */
-    int32_t reserved[7];
+    int32_t n_roots;            /* entries of the root table: one per mesh, fewer when small meshes share a tree */
+    int32_t reserved[6];
 } rt_info_t;
 
 /* replaces: ProgramABC.__init__/initialise creating the GL context (application.py:499-575) */

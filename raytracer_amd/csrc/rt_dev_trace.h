@@ -21,14 +21,17 @@
 //            RT_ACCEL_SAH, whose slots follow another tree, resolves ties the same way).
 //            rem = triangles left in the leaf after this one;
 //            flags = mesh index | RT_TFB_BIT (the mesh's transparentFromBehind).
-//   tri_nrm  3 x float4 per slot (corner normals; .w of the first = mesh index).
+//   tri_hit  4 x float4 per slot (64 B), read only for the WINNER of a query - one scattered cache line per hit:
+//              {nA.xyz, bits(mesh)} {nB.xyz, lo.x} {nC.xyz, lo.y} {lo.z, hi.x, hi.y, hi.z}
+//            corner normals, mesh index and (RT_ACCEL_SAH scenes) the box [lo, hi] of the triangle's leaf in the
+//            REFERENCE's tree (what decides whether a hit found through the SAH tree counts).  Until round 3 normals
+//            (48 B) and boxes (32 B) were two arrays: two lines per hit, which is what a scene that does not fit the L2
+//            (991 k triangles: 80 MB of them) pays for.
 //   nodes    4 x float4 per INTERIOR node: both children's boxes and references
 //              {lo1.xyz, bits(ref1)} {hi1.xyz, bits(ref2)} {lo2.xyz, e1} {hi2.xyz, e2}
 //            ref >= 0: interior record index; ref < 0 and != RT_NONE: leaf, first slot = ~ref;
 //            e = slack of the child's widened slab test (RT_ACCEL_SAH scenes; 0 otherwise).
 //   roots    2 x float4 per mesh: {lo.xyz, bits(ref)} {hi.xyz, e} of the mesh's root node.
-//   tri_box  RT_ACCEL_SAH scenes: 2 x float4 per slot, the box of the triangle's leaf in the
-//            REFERENCE's tree (what decides whether a hit found through the SAH tree counts).
 //   mats     the 80-byte std140 Material of every mesh, as uploaded.
 //   stage    per wave: two slots of one float3 per sample of a JOB (see below); the wave that traced a
 //            job folds it into the accumulator itself, passes in order.
@@ -53,6 +56,17 @@
 #pragma once
 #include "rt_dev_math.h"
 
+// Wave priority (s_setprio, round 3): the traversal steps are bound by vector-instruction issue, the path block by the latency of
+// its dependent loads (winner's rank -> records -> material).  With the traversal at a higher priority than the path block
+// the issue slots go to the waves that can use every one of them, and a wave in its path block fills the gaps it would
+// have left anyway: -1.5 % on the bench frame for any traversal priority 1..3 over path priority 0; the reverse
+// (path block first) +-0, path 1 over traversal 0 +1 % (profiles/r03_k_trace_isa.txt).
+#ifndef RT_PRIO_TRAV
+#define RT_PRIO_TRAV 1
+#endif
+#ifndef RT_PRIO_PATH
+#define RT_PRIO_PATH 0
+#endif
 #define RT_NONE ((int)0x80000000)
 #define RT_BLOCK 256
 #define RT_MISS_RANK 0x7fffffff
@@ -88,15 +102,15 @@ static_assert(sizeof(SphereDev) == 96, "std140 Sphere");
 
 struct DevScene {
     const float4* tri_geo;
-    const float4* tri_nrm;
+    const float4* tri_hit;
     const float4* nodes;
     const float4* roots;
     const MatDev* mats;
     const SphereDev* spheres;
     const int* rank_slot;  // reference rank -> slot (identity unless the scene was built with RT_ACCEL_SAH)
     const int* slot_id;    // triId of each slot
-    const float4* tri_box; // RT_ACCEL_SAH only: 2 x float4 per slot = the box of the triangle's leaf in the REFERENCE's tree
     int n_meshes;
+    int n_roots;          // entries of `roots`: one per mesh, or fewer when the SAH structure groups small meshes into one tree
     int n_spheres;
     int stack_depth;      // node stack entries a lane has in LDS (rt_hip.hip sizes it for full occupancy); DEEP builds: deeper entries go to stack_ovf
     int tlas_root;        // > 32 meshes: record of the top-level tree over the mesh roots; else -1 (roots in LDS)
@@ -342,14 +356,17 @@ __device__ __forceinline__ uint32_t root_mask(int jn, const float4* s_roots, v3 
 
 // SAH structure: the reference only ever tests a triangle whose leaf box IN ITS OWN TREE the ray's
 // slab test passes (the boxes above it nest and float subtract/multiply are monotonic, so they
-// pass too).  The winner found through our tree is checked against that box (tri_box: 2 float4 per
-// slot); in the rounding-level case (~1e-9 of queries) that it fails, the query is run again with
+// pass too).  The winner found through our tree is checked against that box (in its tri_hit
+// record); in the rounding-level case (~1e-9 of queries) that it fails, the query is run again with
 // the check applied to every hit (`gated`), so that the candidate set is exactly the reference's
 // (DESIGN.md 5).
-__device__ __forceinline__ bool ref_leaf_box_passes(const DevScene& S, int slot, v3 org, v3 inv) {
-    const float4* rb = (const float4*)((const char*)S.tri_box + ((uint32_t)slot << 5));
+__device__ __forceinline__ bool ref_leaf_box_of(float4 h1, float4 h2, float4 h3, v3 org, v3 inv) {
     float ta, tb;
-    return box_test(org, inv, rb[0], rb[1], ta, tb);
+    return box_test(org, inv, make_float4(h1.w, h2.w, h3.x, 0.f), make_float4(h3.y, h3.z, h3.w, 0.f), ta, tb);
+}
+__device__ __forceinline__ bool ref_leaf_box_passes(const DevScene& S, int slot, v3 org, v3 inv) {
+    const float4* h = (const float4*)((const char*)S.tri_hit + ((uint32_t)slot << 6));
+    return ref_leaf_box_of(h[1], h[2], h[3], org, inv);
 }
 
 // Device memory reached through a pointer that was read back from the LDS copy of the kernel arguments: say so where
@@ -444,24 +461,29 @@ __device__ __forceinline__ void fold_job(const TraceArgs* Pp, const WaveJobs* wj
     }
 }
 
-template <bool STATS, int CULL, bool FIRST_HIT, bool SAH, bool DEEP>
+template <bool STATS, int CULL, bool FIRST_HIT, bool SAH, bool DEEP, bool MLDS>
 __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) {
     const DevScene& S = a.scene;
     // ---- LDS: mesh root table (2 float4 per mesh), then the per-lane columns
     float4* s_roots = s_mem;
-    const int n_root4 = S.tlas_root >= 0 ? 0 : 2 * S.n_meshes;
+    const int n_root4 = S.tlas_root >= 0 ? 0 : 2 * S.n_roots;
     for (int i = threadIdx.x; i < n_root4; i += RT_BLOCK) s_roots[i] = S.roots[i];
     // ... the mesh materials of the same scenes (80 B each): the path block reads the hit material after the winner's
     // record, a dependent memory round trip that an LDS copy shortens ...
     const int n_mat4 = S.tlas_root >= 0 ? 0 : 5 * S.n_meshes;
     float4* s_mats4 = s_mem + n_root4;
     for (int i = threadIdx.x; i < n_mat4; i += RT_BLOCK) s_mats4[i] = ((const float4*)S.mats)[i];
-    const MatDev* s_mats = n_mat4 ? (const MatDev*)s_mats4 : S.mats;
+    // MLDS instantiations (a root-table scene without spheres: rt_hip.hip::launch_accel): every material the path block reads
+    // is in the LDS copy, and the compiler knows it - ds_read instead of flat_load through a pointer that could be either
+    // (16 of the path block's 28 flat loads; -1.0 % on the bench frame, profiles/r03_k_trace_isa.txt)
+    const MatDev* s_mats = MLDS ? (const MatDev*)s_mats4 : (n_mat4 ? (const MatDev*)s_mats4 : S.mats);
     s_mem += n_mat4;
     // ... and, for a small SAH scene, the rank -> slot table: the first of the path block's dependent loads (winner's
     // rank -> slot -> its records -> its material), each a round trip to the L2 otherwise
     int* s_rank = (int*)(s_mem + n_root4);
     for (int i = threadIdx.x; i < S.rank_lds; i += RT_BLOCK) s_rank[i] = S.rank_slot[i];
+    // (making the LDS home of this table a compile-time fact like MLDS - ds_read instead of flat_load for the first hop of the
+    // path block's dependent chain - measured +0.5 %: the block's loads are then scheduled worse; profiles/r03_k_trace_isa.txt)
     const int* rank_slot = S.rank_lds ? s_rank : S.rank_slot;
     s_mem += (S.rank_lds + 3) / 4;
     // camera and atmosphere constants: read from LDS where the path block needs them, instead of
@@ -519,7 +541,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     float ior = 1.0f;
     bool in_solid = false;
     int hb_key = 0;            // hitBehind test of the ray in flight: the mesh it is inside, or 0 (set at query start)
-    constexpr bool sah = SAH;  // the scene was built with RT_ACCEL_SAH (S.tri_box is set)
+    constexpr bool sah = SAH;  // the scene was built with RT_ACCEL_SAH (the tri_hit records carry the reference's leaf boxes)
     bool gated = false;        // SAH: the query in flight is a repeat with the reference-leaf-box gate on every hit
     Trav tv;
     tv.cur = RT_NONE; tv.sp = 0; tv.lq = 0; tv.k = -1; tv.mask = 0;
@@ -682,11 +704,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 // REFERENCE's tree
                                 const uint64_t m_chk = SAH ? m_gated & lane_mask(inside) : 0;
                                 if (SAH && m_chk != 0) {
-                                    if (in_mask(m_chk)) {
-                                        const float4* rb = (const float4*)((const char*)S.tri_box + ((uint32_t)tv.k << 5));
-                                        float ta, tb;
-                                        inside = box_test(org, inv, rb[0], rb[1], ta, tb);
-                                    }
+                                    if (in_mask(m_chk)) inside = ref_leaf_box_passes(S, tv.k, org, inv);
                                 }
                                 tv.best_t = inside ? t : tv.best_t;
                                 tv.best_rank = inside ? rank_k : tv.best_rank;
@@ -701,9 +719,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
         if (__ballot(mode == M_PATH) == 0) break;                  // every lane is M_DONE (a lane in M_WAIT implies samples in flight, i.e. lanes that traverse)
 
         // =============== path phase: shade the finished query, start the next one ===============
-#ifdef RT_PRIO_PATH   // A/B only (profiles/r03_k_trace_isa.txt): wave priority of the path block / of the traversal loop
         __builtin_amdgcn_s_setprio(RT_PRIO_PATH);
-#endif
         if (STATS) { sch.path_steps++; sch.path_lanes += __popcll(__ballot(mode == M_PATH)); }
         bool need = mode == M_WAIT, start = false, redo = false, completed = false;
         if (mode == M_PATH) {
@@ -744,7 +760,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     } else {
                         const int slot = SAH ? rank_slot[tv.best_rank] : tv.best_rank;
                         const float4* g = S.tri_geo + 4 * (size_t)slot;
-                        const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
+                        const float4 g0 = g[0], g1 = g[1], g2 = g[2];
                         const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
                         const v3 N = V3(g0.w, g1.w, g2.w);
                         backside = dot3(N, dir) > 0.0f;
@@ -752,13 +768,13 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         const float w = length3(cross3(B - A, hit_point - A)) / 2.0f / area;
                         const float u = length3(cross3(C - B, hit_point - B)) / 2.0f / area;
                         const float v = 1.0f - u - w;
-                        const float4* nn = PS.tri_nrm + 3 * (size_t)slot;
+                        const float4* nn = PS.tri_hit + 4 * (size_t)slot;
                         const float4 na = nn[0], nb = nn[1], nc = nn[2];
-                        // loaded together with the triangle's records, so the check adds no memory round trip
-                        if (SAH && !gated) redo = !ref_leaf_box_passes(PS, slot, org, inv) || P.recheck_all != 0;
+                        // the reference's leaf box sits in the same 64-byte record as the normals: no extra memory round trip, no extra line
+                        if (SAH && !gated) redo = !ref_leaf_box_of(nb, nc, nn[3], org, inv) || P.recheck_all != 0;
                         normal = V3(na.x * u + nb.x * v + nc.x * w, na.y * u + nb.y * v + nc.y * w,
                                     na.z * u + nb.z * v + nc.z * w);
-                        hit_id = __float_as_int(g3.z);
+                        hit_id = tv.best_rank;                       // (= the record's rank field g3.z, without waiting for it)
                         hit_mat = __float_as_int(na.w);
                     }
                     if (STATS) cnt.hits += !redo;
@@ -781,7 +797,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         aud.band += own_lo > fma_(best_t, RT_CULL_REL, best_t) + RT_CULL_ABS;
                         aud.behind += own_hi < RT_CULL_BEHIND;
                     }
-                    const MatDev* m = hit_mat < 256 ? &s_mats[hit_mat] : &PS.spheres[hit_mat - 256].material;
+                    const MatDev* m = (MLDS || hit_mat < 256) ? &s_mats[hit_mat] : &PS.spheres[hit_mat - 256].material;
                     const float alpha = m->color[3];
                     bool ended = false, passthrough = redo;   // a query to be repeated changes nothing here
                     if (!redo && alpha < 0.99999f) {                        // :725-736
@@ -815,7 +831,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 float pc0 = atmo.color[0], pc1 = atmo.color[1], pc2 = atmo.color[2];
                                 float pc3 = atmo.color[3], ptr = atmo.transmission;
                                 if (prev_mat >= 0) {
-                                    const MatDev* pm = prev_mat < 256 ? &s_mats[prev_mat] : &PS.spheres[prev_mat - 256].material;
+                                    const MatDev* pm = (MLDS || prev_mat < 256) ? &s_mats[prev_mat] : &PS.spheres[prev_mat - 256].material;
                                     pc0 = pm->color[0]; pc1 = pm->color[1]; pc2 = pm->color[2]; pc3 = pm->color[3];
                                     ptr = pm->transmission;
                                 }
@@ -989,7 +1005,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 } else {
                     tv.cur = RT_NONE;
                     int nearest;
-                    tv.mask = root_mask<STATS, CULL>(__builtin_amdgcn_readfirstlane(PS.n_meshes), s_roots, org, inv, tv.best_t, sah, cnt, nearest);
+                    tv.mask = root_mask<STATS, CULL>(__builtin_amdgcn_readfirstlane(PS.n_roots), s_roots, org, inv, tv.best_t, sah, cnt, nearest);
                     // the mesh whose root box the ray enters first is visited first (a hit there culls the others)
                     if (nearest >= 0) {
                         const int ref = __float_as_int(s_roots[2 * nearest].w);
@@ -999,9 +1015,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 mode = M_TRAV;
             }
         }
-#ifdef RT_PRIO_PATH
         __builtin_amdgcn_s_setprio(RT_PRIO_TRAV);
-#endif
         // The wave is converged here: take the two lane masks anew, for the queries that have just started and (to the
         // same values: node work remains <=> a record in hand, a deferred one or a root left) for those still in flight.
         // A lane without a query keeps the 1/d of its last one; its bit in m_nonfinite is never looked at.

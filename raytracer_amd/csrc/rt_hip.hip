@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void k_pose(PoseArgs a) {
     g[2] = make_float4(C.x, C.y, C.z, N.z);
     const int flags = mesh | (a.mats[mesh].transparentFromBehind ? RT_TFB_BIT : 0);
     g[3] = make_float4(d, __int_as_float(a.slot_rem[k]), __int_as_float(a.slot_rank[k]), __int_as_float(flags));
-    float4* o = a.nrm + 3 * (size_t)k;
+    // hit record (rt_dev_trace.h): normals + mesh; the box fields (.w of [1] and [2], all of [3]) belong to k_ref_leaf_boxes,
+    // which runs after this kernel in every prep of an RT_ACCEL_SAH scene
+    float4* o = a.nrm + 4 * (size_t)k;
     o[0] = make_float4(n[0][0], n[0][1], n[0][2], __int_as_float(mesh));
     o[1] = make_float4(n[1][0], n[1][1], n[1][2], 0.0f);
     o[2] = make_float4(n[2][0], n[2][1], n[2][2], 0.0f);
@@ -142,9 +144,9 @@ __device__ __forceinline__ float box_slack(float4 lo, float4 hi, int sah) {
     return 2.0f * (m * 0x1p-16f + 0x1p-20f);
 }
 
-// one thread per leaf of the REFERENCE's tree: box of its (posed) triangles, written to every member slot
+// one thread per leaf of the REFERENCE's tree: box of its (posed) triangles, written to the hit record of every member slot
 __global__ __launch_bounds__(256) void k_ref_leaf_boxes(const int* leaf_off, const int* leaf_slots, int n_leaves, const float4* geo,
-                                                        float4* tri_box) {
+                                                        float4* tri_hit) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_leaves) return;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -160,8 +162,10 @@ __global__ __launch_bounds__(256) void k_ref_leaf_boxes(const int* leaf_off, con
     }
     for (int q = leaf_off[i]; q < leaf_off[i + 1]; q++) {
         const int k = leaf_slots[q];
-        tri_box[2 * (size_t)k] = make_float4(lo[0], lo[1], lo[2], 0.f);
-        tri_box[2 * (size_t)k + 1] = make_float4(hi[0], hi[1], hi[2], 0.f);
+        float4* h = tri_hit + 4 * (size_t)k;
+        h[1].w = lo[0];
+        h[2].w = lo[1];
+        h[3] = make_float4(lo[2], hi[0], hi[1], hi[2]);
     }
 }
 
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const 
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_slots) return;
     float4 g0 = geo[4 * (size_t)k], g1 = geo[4 * (size_t)k + 1], g2 = geo[4 * (size_t)k + 2], g3 = geo[4 * (size_t)k + 3];
-    float4 a = nrm[3 * (size_t)k], b = nrm[3 * (size_t)k + 1], c = nrm[3 * (size_t)k + 2];
+    float4 a = nrm[4 * (size_t)k], b = nrm[4 * (size_t)k + 1], c = nrm[4 * (size_t)k + 2];
     int id = slot_id[k];
     (void)g3;
     if (id < 0 || id >= n_tris) return;
@@ -209,10 +213,10 @@ __global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const 
 #ifndef RT_WAVES
 #define RT_WAVES 5
 #endif
-template <bool STATS, int CULL, bool FIRST_HIT, bool SAH, bool DEEP>
+template <bool STATS, int CULL, bool FIRST_HIT, bool SAH, bool DEEP, bool MLDS>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES) void k_trace(TraceArgs a) {
     extern __shared__ float4 s_mem[];
-    trace_pixels<STATS, CULL, FIRST_HIT, SAH, DEEP>(a, s_mem);
+    trace_pixels<STATS, CULL, FIRST_HIT, SAH, DEEP, MLDS>(a, s_mem);
 }
 
 // Scratch of rt_render_static, the entry point that allocates nothing (include/rt_hip.h): the work
@@ -378,7 +382,7 @@ struct rt_ctx {
     hipStream_t own_stream = nullptr;   // created by rt_create
     char err[512] = {0};
     // scene (device)
-    DevBuf<float4> rest, geo, nrm, nodes, roots, nbox, tri_box;
+    DevBuf<float4> rest, geo, nrm, nodes, roots, nbox;   // nrm = the 64-byte hit records (normals, mesh, reference leaf box)
     DevBuf<int> ref_leaf_off, ref_leaf_slots;   // RT_ACCEL_SAH: the reference's leaves as lists of our slots
     int n_ref_leaves = 0;
     DevBuf<int> slot_mesh, slot_rem, slot_id, slot_rank, rank_slot, level_nodes, root_v, root_ref;
@@ -421,6 +425,9 @@ struct rt_ctx {
     std::vector<Std140Node> h_nodes;      // topology as uploaded (for rt_read_nodes48)
     MatDev atmo{};
     int n_tris = 0, n_slots = 0, n_meshes = 0, n_nodes = 0, n_visit = 0, n_rec = 0, n_spheres = 0;
+    int n_roots = 0;                      // entries of the root table: one per mesh, or per group of meshes (SAH structure, sah_group_below)
+    int treelet = 8;                      // RT_TREELET: interior records laid out in breadth-first blocks of this many (0 = depth-first order)
+    int sah_group_below = 0;              // RT_SAH_GROUP_BELOW: meshes with fewer triangles share one SAH tree (0 = one tree per mesh)
     int stack_depth = 1;
     int tlas_above = 32;                  // scenes with more meshes than this get the top-level tree (the LDS root mask holds 32)
     int accel = RT_ACCEL_REFERENCE;       // structure built by the next rt_set_scene (rt_set_accel)
@@ -568,17 +575,17 @@ int run_prep(rt_ctx* c) {
     c->flags_pending = false;
     if (c->scene_is_sah && c->n_ref_leaves)
         hipLaunchKernelGGL(k_ref_leaf_boxes, dim3(blocks_for(c->n_ref_leaves)), dim3(256), 0, c->stream, c->ref_leaf_off.p,
-                           c->ref_leaf_slots.p, c->n_ref_leaves, c->geo.p, c->tri_box.p);
+                           c->ref_leaf_slots.p, c->n_ref_leaves, c->geo.p, c->nrm.p);
     for (int l = (int)c->level_off.size() - 2; l >= 0; l--) {
         int n = c->level_off[l + 1] - c->level_off[l];
         if (n <= 0) continue;
         hipLaunchKernelGGL(k_refit_level, dim3(blocks_for(n)), dim3(256), 0, c->stream, c->vnodes.p,
                            c->level_nodes.p + c->level_off[l], n, c->geo.p, c->nbox.p);
     }
-    size_t m = (size_t)std::max(c->n_rec, c->n_meshes);
+    size_t m = (size_t)std::max(c->n_rec, c->n_roots);
     if (m)
         hipLaunchKernelGGL(k_pack_nodes, dim3(blocks_for(m)), dim3(256), 0, c->stream, c->pack.p, c->n_rec, c->nbox.p,
-                           c->nodes.p, c->root_v.p, c->root_ref.p, c->n_meshes, c->roots.p, c->scene_is_sah ? 1 : 0);
+                           c->nodes.p, c->root_v.p, c->root_ref.p, c->n_roots, c->roots.p, c->scene_is_sah ? 1 : 0);
     HIPCK(c, hipGetLastError());
     for (auto& d : c->h_dirty) d = 0;
     c->prep_pending = false;
@@ -588,8 +595,8 @@ int run_prep(rt_ctx* c) {
 int rank_lds_entries(const rt_ctx* c);
 DevScene scene_view(const rt_ctx* c) {
     DevScene s;
-    s.tri_geo = c->geo.p; s.tri_nrm = c->nrm.p; s.nodes = c->nodes.p; s.roots = c->roots.p;
-    s.mats = c->mats.p; s.spheres = c->spheres.p; s.rank_slot = c->rank_slot.p; s.slot_id = c->slot_id.p; s.tri_box = c->scene_is_sah ? c->tri_box.p : nullptr; s.n_meshes = c->n_meshes; s.n_spheres = c->n_spheres;
+    s.tri_geo = c->geo.p; s.tri_hit = c->nrm.p; s.nodes = c->nodes.p; s.roots = c->roots.p;
+    s.mats = c->mats.p; s.spheres = c->spheres.p; s.rank_slot = c->rank_slot.p; s.slot_id = c->slot_id.p; s.n_meshes = c->n_meshes; s.n_roots = c->n_roots; s.n_spheres = c->n_spheres;
     s.stack_depth = c->stack_depth;
     s.tlas_root = c->tlas_root;
     s.rank_lds = rank_lds_entries(c);
@@ -642,25 +649,25 @@ int rank_lds_entries(const rt_ctx* c) {
 }
 
 size_t trace_lds_bytes(const rt_ctx* c, int cap, bool cull, bool sah) {
-    const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : (2 + 5) * c->n_meshes) + (size_t)(rank_lds_entries(c) + 3) / 4 + RT_PC_F4) * sizeof(float4);   // roots, materials, rank table, arguments
+    const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_roots + 5 * c->n_meshes) + (size_t)(rank_lds_entries(c) + 3) / 4 + RT_PC_F4) * sizeof(float4);   // roots, materials, rank table, arguments
     const size_t lq = RT_LQ_OF(sah);
     return fixed + ((size_t)cap + lq) * RT_BLOCK * 4 + (cull ? lq * RT_BLOCK * 2 : 0);
 }
 
-template <bool STATS, int CULL, bool FIRST, bool SAH, bool DEEP>
+template <bool STATS, int CULL, bool FIRST, bool SAH, bool DEEP, bool MLDS>
 int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     if (c->blocks_per_cu[key] <= 0) {
         int nb = 0, nb_best = 0;
         for (;;) {
-            HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, trace_lds_bytes(c, cap, CULL, SAH)));
+            HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS>, RT_BLOCK, trace_lds_bytes(c, cap, CULL, SAH)));
             if (!DEEP || nb >= RT_WAVES || cap <= RT_MIN_STACK_LDS || c->stack_lds_force > 0) break;
             // lds_stack_entries guessed the allocation granule wrong, or registers are the limit
             if (nb_best == 0)
-                HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_best, k_trace<STATS, CULL, FIRST, SAH, DEEP>, RT_BLOCK, trace_lds_bytes(c, RT_MIN_STACK_LDS, CULL, SAH)));
+                HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_best, k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS>, RT_BLOCK, trace_lds_bytes(c, RT_MIN_STACK_LDS, CULL, SAH)));
             if (nb >= nb_best) break;
             cap--;
         }
-        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (%d mesh roots)", trace_lds_bytes(c, cap, CULL, SAH), c->n_meshes);
+        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (%d roots, %d meshes)", trace_lds_bytes(c, cap, CULL, SAH), c->n_roots, c->n_meshes);
         c->blocks_per_cu[key] = nb;
         c->stack_lds[key] = cap;
         if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] k_trace variant %d: %d of %d node stack entries in LDS, %zu bytes of LDS, %d workgroups per CU\n", key, cap, c->stack_depth, trace_lds_bytes(c, cap, CULL, SAH), nb);
@@ -709,7 +716,7 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     c->last_lds_bytes = (int)lds;
     c->last_blocks_per_cu = c->blocks_per_cu[key];
     HIPCK(c, hipMemsetAsync(b.work_counter, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST, SAH, DEEP>), dim3(grid), dim3(RT_BLOCK), lds, c->stream, b);
+    hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS>), dim3(grid), dim3(RT_BLOCK), lds, c->stream, b);
     return RT_OK;
 }
 
@@ -724,11 +731,21 @@ int lds_stack_entries(const rt_ctx* c) {
     return std::max(RT_MIN_STACK_LDS, std::min(c->stack_depth, fit));
 }
 
+template <bool STATS, int CULL, bool FIRST, bool SAH, bool DEEP>
+int launch_mats(rt_ctx* c, const TraceArgs& a, int key, int cap) {
+    // MLDS: the materials of every possible hit are in k_trace's LDS copy (a scene with a root table, i.e. without a top-level
+    // tree, and without spheres) - proved here on the host, per launch.  Only the render kernels have the instantiation.
+    if constexpr (!STATS && !FIRST) {
+        if (c->tlas_root < 0 && c->n_spheres == 0 && c->n_meshes > 0) return launch_one<STATS, CULL, FIRST, SAH, DEEP, true>(c, a, key, cap);
+    }
+    return launch_one<STATS, CULL, FIRST, SAH, DEEP, false>(c, a, key, cap);
+}
+
 template <bool STATS, int CULL, bool FIRST>
 int launch_accel(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     const bool deep = cap < c->stack_depth;
-    if (c->scene_is_sah) return deep ? launch_one<STATS, CULL, FIRST, true, true>(c, a, key, cap) : launch_one<STATS, CULL, FIRST, true, false>(c, a, key, cap);
-    return deep ? launch_one<STATS, CULL, FIRST, false, true>(c, a, key, cap) : launch_one<STATS, CULL, FIRST, false, false>(c, a, key, cap);
+    if (c->scene_is_sah) return deep ? launch_mats<STATS, CULL, FIRST, true, true>(c, a, key, cap) : launch_mats<STATS, CULL, FIRST, true, false>(c, a, key, cap);
+    return deep ? launch_mats<STATS, CULL, FIRST, false, true>(c, a, key, cap) : launch_mats<STATS, CULL, FIRST, false, false>(c, a, key, cap);
 }
 
 int launch_trace(rt_ctx* c, const TraceArgs& a, bool first_hit) {
@@ -825,6 +842,8 @@ int rt_create(int device, rt_ctx** out) {
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return RT_E_DEVICE; }
     c->stream = c->own_stream;
     if (const char* e = getenv("RT_SAH_LEAF")) c->sah_leaf = std::max(1, std::min(64, atoi(e)));
+    if (const char* e = getenv("RT_SAH_GROUP_BELOW")) c->sah_group_below = std::max(0, atoi(e));
+    if (const char* e = getenv("RT_TREELET")) c->treelet = std::max(0, atoi(e));
     if (const char* e = getenv("RT_TLAS_STATIC")) c->tlas_static = atoi(e) != 0;
     if (const char* e = getenv("RT_TLAS_ABOVE")) c->tlas_above = std::max(1, std::min(32, atoi(e)));
     if (const char* e = getenv("RT_NODE_BIAS")) c->node_bias = atoi(e);
@@ -860,7 +879,7 @@ int rt_create(int device, rt_ctx** out) {
 
 static void free_scene(rt_ctx* c) {
     c->rest.release(); c->geo.release(); c->nrm.release(); c->nodes.release(); c->roots.release(); c->nbox.release();
-    c->slot_mesh.release(); c->slot_rem.release(); c->slot_id.release(); c->slot_rank.release(); c->rank_slot.release(); c->tri_box.release(); c->ref_leaf_off.release(); c->ref_leaf_slots.release(); c->level_nodes.release();
+    c->slot_mesh.release(); c->slot_rem.release(); c->slot_id.release(); c->slot_rank.release(); c->rank_slot.release(); c->ref_leaf_off.release(); c->ref_leaf_slots.release(); c->level_nodes.release();
     c->root_v.release(); c->root_ref.release(); c->xf.release(); c->dirty.release(); c->vnodes.release();
     c->pack.release(); c->mats.release(); c->spheres.release();
     c->have_scene = false;
@@ -924,21 +943,25 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     std::vector<VNode> vnodes;
     std::vector<int> vdepth, vnode_id;
     std::vector<PackInfo> pack;
-    std::vector<int> root_v(n_meshes), root_ref(n_meshes);
+    std::vector<int> root_v, root_ref;     // per root of the walk (= per mesh, or per group of meshes of the SAH structure)
     std::vector<float4> rest;
     std::vector<int> slot_mesh, slot_rem, slot_id;
     std::vector<int> first_visit;
     int max_depth = 0;
     // walks the trees `wn` (roots `wroot[j]`, leaf lists in `wids`) and fills the vectors above
     std::vector<char> listed;              // triangle already met in a leaf of this walk
-    auto walk = [&](const Std140Node* wn, int wn_count, const int32_t* wids, const std::vector<int>& wroot) -> int {
+    // (per_mesh: root j holds exactly the triangles of mesh j, as the reference's trees do; else a root may hold several meshes)
+    auto walk = [&](const Std140Node* wn, int wn_count, const int32_t* wids, const std::vector<int>& wroot, bool per_mesh) -> int {
         vnodes.clear(); vdepth.clear(); vnode_id.clear(); pack.clear(); rest.clear();
         slot_mesh.clear(); slot_rem.clear(); slot_id.clear();
         listed.assign((size_t)n_tris, 0);
         first_visit.assign(wn_count, -1);
         max_depth = 0;
         const size_t visit_cap = 4 * (size_t)wn_count + 16;
-        for (int j = 0; j < n_meshes; j++) {
+        const int n_walk_roots = (int)wroot.size();
+        root_v.assign(n_walk_roots, 0);
+        root_ref.assign(n_walk_roots, RT_NONE);
+        for (int j = 0; j < n_walk_roots; j++) {
             std::vector<Visit> st;
             st.push_back({wroot[j], 0, -1, 0});
             while (!st.empty()) {
@@ -952,7 +975,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
                 vnode_id.push_back(cur.node);
                 if (first_visit[cur.node] < 0) first_visit[cur.node] = v;
                 if (cur.depth > max_depth) max_depth = cur.depth;
-                if (cur.depth + 1 > RT_MAX_STACK) return fail(c, RT_E_LIMIT, "mesh %d: BVH deeper than %d", j, RT_MAX_STACK - 1);
+                if (cur.depth + 1 > RT_MAX_STACK) return fail(c, RT_E_LIMIT, "root %d: BVH deeper than %d", j, RT_MAX_STACK - 1);
                 int ref;
                 const bool leaf = n.c1 < 0 && n.c2 < 0;
                 if (leaf) {
@@ -960,7 +983,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
                     vnodes[v].count = n.cnt;
                     for (int i = 0; i < n.cnt; i++) {
                         const Std140Tri& t = tris[wids[n.off + i]];
-                        if (t.meshIndex != j)
+                        if (per_mesh && t.meshIndex != j)
                             return fail(c, RT_E_ARG, "triangle %d in the BVH of mesh %d belongs to mesh %d", t.triId, j, t.meshIndex);
                         // the reference's builder puts every triangle into exactly one leaf (chunker.py:216-244);
                         // a second listing would make rank and triId disagree for the previous-hit skip (:600)
@@ -968,7 +991,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
                         listed[t.triId] = 1;
                         const float* src[6] = {t.posA, t.posB, t.posC, t.nA, t.nB, t.nC};
                         for (int q = 0; q < 6; q++) rest.push_back(make_float4(src[q][0], src[q][1], src[q][2], 0.f));
-                        slot_mesh.push_back(j);
+                        slot_mesh.push_back(t.meshIndex);
                         slot_rem.push_back(n.cnt - 1 - i);
                         slot_id.push_back(t.triId);
                     }
@@ -999,7 +1022,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     };
     std::vector<int> ref_roots(n_meshes);
     for (int j = 0; j < n_meshes; j++) ref_roots[j] = meshes[j].node0Id;
-    int wrc = walk(nodes, n_nodes, leaf_ids, ref_roots);
+    int wrc = walk(nodes, n_nodes, leaf_ids, ref_roots, true);
     if (wrc) return wrc;
     // rank = position in the reference's traversal order: what decides ties (rt_dev_trace.h)
     std::vector<int> slot_rank(slot_id.size()), rank_slot(slot_id.size());
@@ -1021,13 +1044,29 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
             if (rank_of_tri[slot_id[k]] < 0) rank_of_tri[slot_id[k]] = (int)k;
         std::vector<RtNode48> sn;
         std::vector<int32_t> sids;
-        std::vector<int> sroots(n_meshes);
+        std::vector<int> sroots;
         {
             std::vector<std::vector<int32_t>> per_mesh(n_meshes);
             for (size_t k = 0; k < slot_id.size(); k++)
                 if (rank_of_tri[slot_id[k]] == (int)k) per_mesh[slot_mesh[k]].push_back(slot_id[k]);
+            // Groups: meshes with fewer than `sah_group_below` triangles share ONE tree (the eight wall / light / ground meshes of
+            // the Suzanne room: 2 roots to test per ray instead of 9).  Any structure over the same triangles gives the
+            // reference's result - ranks decide ties, the flag word of each triangle carries its mesh, the winner is checked
+            // against its reference leaf box - so grouping is a matter of speed only.  The topology is built from the positions
+            // handed in (rest poses): it is a good one as long as the members of a group keep their relative poses; the boxes
+            // are refit from the posed triangles whatever the topology.  Root-table scenes only (a top-level tree is built over
+            // per-mesh roots).
+            std::vector<std::vector<int32_t>> per_group;
+            int small_group = -1;
             for (int j = 0; j < n_meshes; j++) {
-                const std::vector<int32_t>& ids = per_mesh[j];
+                const bool merge = c->sah_group_below > 0 && n_meshes <= c->tlas_above && !per_mesh[j].empty() && (int)per_mesh[j].size() < c->sah_group_below;
+                if (!merge) { per_group.push_back(std::move(per_mesh[j])); continue; }
+                if (small_group < 0) { small_group = (int)per_group.size(); per_group.emplace_back(); }
+                per_group[small_group].insert(per_group[small_group].end(), per_mesh[j].begin(), per_mesh[j].end());
+            }
+            sroots.resize(per_group.size());
+            for (int j = 0; j < (int)per_group.size(); j++) {
+                const std::vector<int32_t>& ids = per_group[j];
                 if (ids.empty()) {                                   // keep the (empty) reference leaf
                     RtNode48 e;
                     std::memset(&e, 0, sizeof(e));
@@ -1047,12 +1086,57 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
             }
         }
         static_assert(sizeof(RtNode48) == sizeof(Std140Node), "node images");
-        if ((wrc = walk((const Std140Node*)sn.data(), (int)sn.size(), sids.data(), sroots))) return wrc;
+        if ((wrc = walk((const Std140Node*)sn.data(), (int)sn.size(), sids.data(), sroots, false))) return wrc;
         slot_rank.resize(slot_id.size());
         rank_slot.assign(n_tris > 0 ? (size_t)*std::max_element(rank_of_tri.begin(), rank_of_tri.end()) + 1 : 0, 0);
         for (size_t k = 0; k < slot_id.size(); k++) {
             slot_rank[k] = rank_of_tri[slot_id[k]];
             rank_slot[slot_rank[k]] = (int)k;
+        }
+    }
+    // ---- record order: treelets ----
+    // The walk numbers interior records depth-first (parent, then the subtree visited first).  For a scene whose records do
+    // not fit the L2 (991 k triangles: 25 MB of them) that strews the hot top levels over the whole array and makes a descent
+    // touch one cache line per level.  Records are addressed by index only, so they can be laid out freely: breadth-first
+    // blocks of `treelet` records (a subtree of ~log2(treelet) levels in consecutive lines), the blocks themselves in
+    // depth-first order - the top of every tree first, each subtree's blocks together.  Host-only; traversal order, ranks and
+    // slots are untouched, so the image cannot change.  RT_TREELET=0 keeps the depth-first order.
+    if (c->treelet > 1 && pack.size() > 2) {
+        std::vector<int> order;                       // new index -> old index
+        order.reserve(pack.size());
+        std::vector<int> roots_todo;
+        for (int j = (int)root_ref.size() - 1; j >= 0; j--)
+            if (root_ref[j] >= 0) roots_todo.push_back(root_ref[j]);
+        std::vector<int> q, frontier;
+        while (!roots_todo.empty()) {
+            const int r = roots_todo.back();
+            roots_todo.pop_back();
+            q.assign(1, r);
+            frontier.clear();
+            int taken = 0;
+            for (size_t h = 0; h < q.size(); h++) {
+                const int x = q[h];
+                if (taken == c->treelet) { frontier.push_back(x); continue; }
+                order.push_back(x);
+                taken++;
+                if (pack[x].ref1 >= 0) q.push_back(pack[x].ref1);
+                if (pack[x].ref2 >= 0) q.push_back(pack[x].ref2);
+            }
+            for (size_t h = frontier.size(); h-- > 0;) roots_todo.push_back(frontier[h]);
+        }
+        if (order.size() == pack.size()) {            // (always: every record hangs off a root)
+            std::vector<int> new_of(pack.size());
+            for (size_t n = 0; n < order.size(); n++) new_of[order[n]] = (int)n;
+            std::vector<PackInfo> np(pack.size());
+            for (size_t n = 0; n < order.size(); n++) {
+                PackInfo pi = pack[order[n]];
+                if (pi.ref1 >= 0) pi.ref1 = new_of[pi.ref1];
+                if (pi.ref2 >= 0) pi.ref2 = new_of[pi.ref2];
+                np[n] = pi;
+            }
+            pack.swap(np);
+            for (int& rr : root_ref)
+                if (rr >= 0) rr = new_of[rr];
         }
     }
     std::vector<int> ref_leaf_off, ref_leaf_slots;
@@ -1097,6 +1181,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     // ---- upload ----
     free_scene(c);
     c->n_tris = n_tris; c->n_meshes = n_meshes; c->n_nodes = n_nodes; c->n_spheres = n_spheres;
+    c->n_roots = (int)root_v.size();
     c->n_slots = (int)slot_id.size(); c->n_visit = (int)vnodes.size(); c->n_rec = (int)pack.size();
     int rc;
     if ((rc = upload(c, c->rest, rest))) return rc;
@@ -1108,7 +1193,6 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     if ((rc = upload(c, c->ref_leaf_off, ref_leaf_off))) return rc;
     if ((rc = upload(c, c->ref_leaf_slots, ref_leaf_slots))) return rc;
     c->n_ref_leaves = sah ? (int)ref_leaves.size() : 0;
-    if (sah) HIPCK(c, c->tri_box.alloc(2 * (size_t)slot_id.size()));
     if ((rc = upload(c, c->vnodes, vnodes))) return rc;
     if ((rc = upload(c, c->pack, pack))) return rc;
     if ((rc = upload(c, c->level_nodes, level_nodes))) return rc;
@@ -1122,9 +1206,9 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     if ((rc = upload(c, c->spheres, sph))) return rc;
     std::memcpy(&c->atmo, atmosphere80, 80);
     HIPCK(c, c->geo.alloc(4 * (size_t)c->n_slots));
-    HIPCK(c, c->nrm.alloc(3 * (size_t)c->n_slots));
+    HIPCK(c, c->nrm.alloc(4 * (size_t)c->n_slots));
     HIPCK(c, c->nodes.alloc(4 * (size_t)c->n_rec));
-    HIPCK(c, c->roots.alloc(2 * (size_t)n_meshes));
+    HIPCK(c, c->roots.alloc(2 * (size_t)c->n_roots));
     HIPCK(c, c->nbox.alloc(2 * (size_t)c->n_visit));
     HIPCK(c, c->xf.alloc(16 * (size_t)std::max(n_meshes, 1)));
     HIPCK(c, c->dirty.alloc((size_t)std::max(n_meshes, 1)));
@@ -1484,6 +1568,7 @@ int rt_get_info(rt_ctx* c, rt_info_t* o) {
     o->lds_bytes = c->last_lds_bytes;
     o->workgroups_per_cu = c->last_blocks_per_cu;
     o->top_level_rebuilds = c->tlas_rebuilds;
+    o->n_roots = c->n_roots;
     return RT_OK;
 }
 
