@@ -221,6 +221,14 @@ int rt_read_accum(rt_ctx* ctx, float* out_whc, uint64_t* n_passes_out);
 int rt_read_mean(rt_ctx* ctx, float* out_whc);
 /* tell the context how many passes an externally combined (all-reduced) SUM now holds */
 int rt_set_accum_passes(rt_ctx* ctx, uint64_t n_passes);
+/* NO counterpart in the reference (it has no multi-GPU path).  The one exchange step of the spp-sharded path (SURVEY.md
+ * 8(e)) for a host without torch: ncclAllReduce(sum, float32) of the W*H*3 accumulator over `nccl_comm` (an ncclComm_t
+ * the caller created, one rank per GPU), in place, on the context's stream - ordered after the renders, no host
+ * synchronisation - and the accumulator then counts as holding `total_passes` passes (what rt_read_mean divides by).
+ * The shards must have been rendered with RT_ACCUM_SUM.  RCCL is resolved at the first call (an instance the process
+ * has already loaded - the one the communicator came from - else librccl.so.1; RT_RCCL_LIB names another): the library
+ * does not link it.  RT_E_DEVICE if RCCL cannot be found or the collective fails.  Oracle: RT_E_STATE (single process). */
+int rt_allreduce_sum(rt_ctx* ctx, void* nccl_comm, uint64_t total_passes);
 
 /* Traversal mode.  RT_CULL_OFF (default) = STRICT: every box the reference would open is opened,
  * so results equal the oracle bit-for-bit.  RT_CULL_ON: boxes (a) wholly beyond the current closest

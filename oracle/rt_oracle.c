@@ -1046,6 +1046,8 @@ int rt_get_info(rt_ctx* c, rt_info_t* o) {
     return RT_OK;
 }
 int rt_sync(rt_ctx* c) { return c ? RT_OK : RT_E_ARG; }
+/* the oracle is a single-process checker: there is nothing to combine with */
+int rt_allreduce_sum(rt_ctx* c, void* comm, uint64_t total) { (void)comm; (void)total; if (!c) return RT_E_ARG; FAIL(c, RT_E_STATE, "the oracle has no collective"); }
 int rt_set_cull(rt_ctx* c, int e) { (void)e; return c ? RT_OK : RT_E_ARG; } /* the oracle never culls */
 int rt_set_accel(rt_ctx* c, int accel) { (void)accel; return c ? RT_OK : RT_E_ARG; }   /* one structure only: the reference's */
 int rt_set_stream(rt_ctx* c, void* s) { (void)s; return c ? RT_OK : RT_E_ARG; }

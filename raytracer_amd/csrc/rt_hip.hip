@@ -20,6 +20,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -DRT_WAVES=6
 // (see __graft_entry__.py).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1588,6 +1589,54 @@ int rt_get_stats(rt_ctx* c, rt_stats_t* o) {
     for (int q = 0; q < 6; q++) c->st.sched[q] = h[4 + q];
     for (int q = 0; q < 3; q++) c->st.cull_audit[q] = h[10 + q];
     *o = c->st;
+    return RT_OK;
+}
+
+// ---- rt_allreduce_sum: the one exchange step of the spp-sharded path, for hosts without torch ----
+// RCCL is resolved at the first call, not linked: the library has no RCCL dependency for the callers that never combine
+// shards.  The communicator belongs to ONE RCCL instance (a process can hold several: torch ships its own), so the
+// instance is looked for in this order: RT_RCCL_LIB (a path), an instance the process has already loaded under the
+// usual names (RTLD_NOLOAD: the one the caller created its communicator with), then a fresh load of librccl.so.1.
+namespace {
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*nccl_errstr_fn)(int);
+struct RcclApi { nccl_allreduce_fn allreduce = nullptr; nccl_errstr_fn errstr = nullptr; bool tried = false; char from[256] = {0}; };
+RcclApi g_rccl;
+void load_rccl() {
+    if (g_rccl.tried) return;
+    g_rccl.tried = true;
+    void* h = nullptr;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    if (const char* e = getenv("RT_RCCL_LIB")) {
+        h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+        snprintf(g_rccl.from, sizeof(g_rccl.from), "%s (RT_RCCL_LIB)", e);
+    }
+    for (int k = 0; !h && k < 2; k++) {
+        h = dlopen(names[k], RTLD_NOW | RTLD_NOLOAD);
+        if (h) snprintf(g_rccl.from, sizeof(g_rccl.from), "%s (already loaded)", names[k]);
+    }
+    for (int k = 0; !h && k < 1; k++) {
+        h = dlopen(names[k], RTLD_NOW | RTLD_LOCAL);
+        if (h) snprintf(g_rccl.from, sizeof(g_rccl.from), "%s", names[k]);
+    }
+    if (!h) return;
+    g_rccl.allreduce = (nccl_allreduce_fn)dlsym(h, "ncclAllReduce");
+    g_rccl.errstr = (nccl_errstr_fn)dlsym(h, "ncclGetErrorString");
+}
+}  // namespace
+
+int rt_allreduce_sum(rt_ctx* c, void* nccl_comm, uint64_t total_passes) {
+    if (!c || !nccl_comm) return RT_E_ARG;
+    if (!c->accum) return fail(c, RT_E_STATE, "no image size");
+    if (!c->sum_mode && c->n_accum > 0) return fail(c, RT_E_STATE, "the accumulator holds a running mean: render the shards with RT_ACCUM_SUM");
+    load_rccl();
+    if (!g_rccl.allreduce) return fail(c, RT_E_DEVICE, "RCCL not found (librccl.so.1; RT_RCCL_LIB names another)");
+    HIPCK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->cam.width * c->cam.height * 3;
+    const int rc = g_rccl.allreduce(c->accum, c->accum, n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, nccl_comm, c->stream);
+    if (rc != 0) return fail(c, RT_E_DEVICE, "ncclAllReduce (%s): %s", g_rccl.from, g_rccl.errstr ? g_rccl.errstr(rc) : "error");
+    c->n_accum = total_passes;
+    c->sum_mode = true;
     return RT_OK;
 }
 

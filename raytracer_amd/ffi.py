@@ -78,6 +78,7 @@ _SIGNATURES = {
     "rt_read_accum": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint64)]),
     "rt_read_mean": (C.c_int, [_vp, _vp]),
     "rt_set_accum_passes": (C.c_int, [_vp, C.c_uint64]),
+    "rt_allreduce_sum": (C.c_int, [_vp, _vp, C.c_uint64]),
     "rt_set_cull": (C.c_int, [_vp, C.c_int]),
     "rt_set_accel": (C.c_int, [_vp, C.c_int]),
     "rt_enable_stats": (C.c_int, [_vp, C.c_int]),
@@ -239,6 +240,10 @@ class RtContext:
 
     def set_accum_passes(self, n: int) -> None:
         self._ck(self.lib.dll.rt_set_accum_passes(self._h, n), "rt_set_accum_passes")
+
+    def allreduce_sum(self, nccl_comm: int, total_passes: int) -> None:
+        """ncclAllReduce(sum) of the accumulator over an ncclComm_t handle, on the context's stream (rt_hip.h)."""
+        self._ck(self.lib.dll.rt_allreduce_sum(self._h, _vp(nccl_comm), total_passes), "rt_allreduce_sum")
 
     # -- work ------------------------------------------------------------------------------------
     def render(self, first_pass: int, n_passes: int, pass_stride: int = 1, rays_per_pixel: int = 1,

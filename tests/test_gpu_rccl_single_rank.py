@@ -105,3 +105,51 @@ def test_animation_runner_gathers_over_rccl_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["frames"] == 3 and line["frames_held_by_rank0"] == 3 and line["value"] > 0
+
+
+_C_COLLECTIVE = r"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from conftest import build_suzanne
+from raytracer_amd.ffi import RT_ACCUM_SUM, RtError, RtLib
+
+lib = RtLib()
+sc = build_suzanne(0)
+ctx = lib.create(0)                        # hipSetDevice(0) before the communicator is made
+ctx.load_scene(sc); ctx.load_camera(sc.cam); ctx.resize(96, 54)
+rccl = ctypes.CDLL("librccl.so.1", mode=ctypes.RTLD_GLOBAL)     # what a C host links; rt_allreduce_sum finds this instance
+class Uid(ctypes.Structure):
+    _fields_ = [("internal", ctypes.c_char * 128)]
+uid, comm = Uid(), ctypes.c_void_p()
+assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, Uid, ctypes.c_int]
+assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+ctx.render(1, 3, 2, 1, 4, RT_ACCUM_SUM)    # the shard of rank 0 of 2: passes 1, 3, 5
+before = ctx.read_accum()[0].copy()
+ctx.allreduce_sum(comm.value, 3)           # on the context's stream, no host synchronisation in between
+after, n = ctx.read_accum()
+assert n == 3 and before.max() > 0 and np.array_equal(before.view(np.uint32), after.view(np.uint32))
+assert np.array_equal(ctx.read_mean(), before / np.float32(3))
+ctx.reset_accum(); ctx.render(1, 2, 1, 1, 4, 0)
+try:
+    ctx.allreduce_sum(comm.value, 2)       # a running mean cannot be summed over ranks
+    raise SystemExit("a mean-mode accumulator was accepted")
+except RtError as e:
+    assert e.code == -2, e
+rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+rccl.ncclCommDestroy(comm)
+ctx.close()
+print("c-collective ok")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_c_abi_collective_over_an_rccl_communicator_of_one_rank():
+    """rt_allreduce_sum: the exchange step for a host without torch - an ncclComm_t made through RCCL's own C
+    API, the all-reduce issued by the library on the render's stream.  One rank is what a one-GPU box can do: the sum over one
+    rank leaves the accumulator bit for bit, the pass count becomes the job's."""
+    code = _C_COLLECTIVE.format(root=str(ROOT), tests=str(ROOT / "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "c-collective ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

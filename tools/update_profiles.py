@@ -10,6 +10,10 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 tag, wl, src, note = sys.argv[1], sys.argv[2], Path(sys.argv[3]), sys.argv[4]
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+
+W, H, P = (bench.WORKLOADS[wl][k] for k in ("width", "height", "passes"))
 prof = ROOT / "profiles"
 shutil.copy(src / "trace" / "trace_kernel_stats.csv", prof / f"{tag}_{wl}_kernel_stats.csv")
 shutil.copy(src / "summary.txt", prof / f"{tag}_{wl}_rocprof_summary.txt")
@@ -33,7 +37,9 @@ latest[wl] = {
     "file": f"profiles/{tag}_{wl}_rocprof_summary.txt",
     "commit": note,
     "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes) -- " + pmc["command"],
-    "algorithmic_hbm_bytes_per_launch": old.get("algorithmic_hbm_bytes_per_launch"),
+    # the accumulator, 12 B read + 12 B written per pixel per launch; the staging stream is design overhead
+    "algorithmic_hbm_bytes_per_launch": 24 * W * H,
+    "design_overhead_bytes_per_launch": 24 * W * H * P,
     "avg_launch_ms_rocprof": avg,
     "launches_traced": calls,
 }
