@@ -595,6 +595,10 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         // the branches below as 0/1 values in vector registers and compares them again - a dozen vector
                         // instructions of a step that is bound by vector issue.
                         uint64_t m_h1, m_h2;
+                        // An absent child (reference RT_NONE: a node with one child, an empty leaf) carries an all-NaN box and slack
+                        // (k_pack_nodes): in the min/max form every slab value, hence the interval, is NaN, and NaN <= x is false -
+                        // the test fails by itself, no compare of the reference needed (two vector instructions per node step: -0.9 %).
+                        // The compare ladder reads NaN as "not disjoint" (as the reference does), so those branches do test it.
                         if ((m_nonfinite & lane_mask(true)) == 0) {
                             box_test_finite(org, inv, n0, n1, t1a, t1b);
                             box_test_finite(org, inv, n2, n3, t2a, t2b);
@@ -607,15 +611,13 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 m_h2 = lane_mask(t2a <= t2b);
                             }
                         } else if (!sah) {                          // a lane has an exactly zero direction component
-                            m_h1 = lane_mask(box_test(org, inv, n0, n1, t1a, t1b));
-                            m_h2 = lane_mask(box_test(org, inv, n2, n3, t2a, t2b));
+                            m_h1 = lane_mask(box_test(org, inv, n0, n1, t1a, t1b)) & lane_mask(ref1 != RT_NONE);
+                            m_h2 = lane_mask(box_test(org, inv, n2, n3, t2a, t2b)) & lane_mask(ref2 != RT_NONE);
                         } else {
                             const float mo = sah_org(org);
-                            m_h1 = lane_mask(sah_box_test_any(org, inv, n0, n1, n2.w, mo, t1a, t1b));
-                            m_h2 = lane_mask(sah_box_test_any(org, inv, n2, n3, n3.w, mo, t2a, t2b));
+                            m_h1 = lane_mask(sah_box_test_any(org, inv, n0, n1, n2.w, mo, t1a, t1b)) & lane_mask(ref1 != RT_NONE);
+                            m_h2 = lane_mask(sah_box_test_any(org, inv, n2, n3, n3.w, mo, t2a, t2b)) & lane_mask(ref2 != RT_NONE);
                         }
-                        m_h1 &= lane_mask(ref1 != RT_NONE);
-                        m_h2 &= lane_mask(ref2 != RT_NONE);
                         if (CULL) {                                 // culled(): NaN never culls
                             const float beyond = fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS;
                             if (CULL == 1) {

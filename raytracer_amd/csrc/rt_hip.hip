@@ -175,11 +175,18 @@ __global__ __launch_bounds__(256) void k_pack_nodes(const PackInfo* pi, int n_re
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_rec) {
         PackInfo p = pi[i];
-        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 lo1 = p.c1 >= 0 ? nbox[2 * (size_t)p.c1] : z, hi1 = p.c1 >= 0 ? nbox[2 * (size_t)p.c1 + 1] : z;
-        float4 lo2 = p.c2 >= 0 ? nbox[2 * (size_t)p.c2] : z, hi2 = p.c2 >= 0 ? nbox[2 * (size_t)p.c2 + 1] : z;
-        lo2.w = box_slack(lo1, hi1, pad && p.c1 >= 0);
-        hi2.w = box_slack(lo2, hi2, pad && p.c2 >= 0);
+        // An absent child (ref RT_NONE) gets an all-NaN box and a NaN slack: in the min/max form of the slab test (rays with finite
+        // 1/d) every slab value and so the interval is NaN, and "NaN <= x" is false - it can never be entered, whatever the ray,
+        // which is what lets k_trace drop the compare of the reference there.  (No finite or infinite box has that property: the
+        // min/max form is symmetric in lo and hi, so an inverted box is the whole line.)  An EMPTY leaf that the walk kept as a
+        // child (c >= 0, no triangles) has ref RT_NONE too: same treatment, whatever the refit wrote for it.
+        const float qn = __int_as_float(0x7fc00000);
+        const float4 zn = make_float4(qn, qn, qn, qn);
+        const bool a1 = p.c1 >= 0 && p.ref1 != RT_NONE, a2 = p.c2 >= 0 && p.ref2 != RT_NONE;
+        float4 lo1 = a1 ? nbox[2 * (size_t)p.c1] : zn, hi1 = a1 ? nbox[2 * (size_t)p.c1 + 1] : zn;
+        float4 lo2 = a2 ? nbox[2 * (size_t)p.c2] : zn, hi2 = a2 ? nbox[2 * (size_t)p.c2 + 1] : zn;
+        lo2.w = a1 ? box_slack(lo1, hi1, pad) : qn;
+        hi2.w = a2 ? box_slack(lo2, hi2, pad) : qn;
         lo1.w = __int_as_float(p.ref1);
         hi1.w = __int_as_float(p.ref2);
         float4* o = nodes + 4 * (size_t)i;

@@ -281,3 +281,58 @@ def test_set_cull_rejects_unknown_modes(hip_lib):
         c.set_cull(3)
     assert e.value.code == -1
     c.close()
+
+
+def _pruned_buffers(sc, seed):
+    """The scene's upload buffers with nodes the reference's builder never makes but its shader handles (:562-584): interior
+    nodes that lost one child (childId = -1) and leaves emptied to zero triangles - what becomes RT_NONE in the device records."""
+    from raytracer_amd.scripts import functions as Fn
+
+    Fn.pose_dirty_meshes_on_host(sc)
+    b = Fn.export_scene_buffers(sc, rest_pose=False)
+    nodes = b["nodes48"].copy()
+    r = np.random.default_rng(7000 + seed)
+    interior = np.flatnonzero((nodes["childId1"] >= 0) & (nodes["childId2"] >= 0))
+    for i in interior[r.random(len(interior)) < 0.3]:
+        nodes[i]["childId2" if r.random() < 0.5 else "childId1"] = -1
+    leaves = np.flatnonzero((nodes["childId1"] < 0) & (nodes["childId2"] < 0))
+    for i in leaves[r.random(len(leaves)) < 0.1]:
+        nodes[i]["childObjCount"] = 0
+    b["nodes48"] = nodes
+    return b, int(len(interior)), int((nodes["childObjCount"][leaves] == 0).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [("grid", 0, (1, 129)), ("grid", 1, (129, 1)), ("grid", 2, (48, 27)), ("random", 3, (64, 36)),
+                                  ("random", 5, (64, 36)), ("random", 11, (64, 36))])
+def test_one_child_nodes_and_empty_leaves(oracle_lib, hip_lib, case):
+    """Absent children carry NaN boxes on the device and the min/max slab test alone keeps rays out of them (k_pack_nodes,
+    rt_dev_trace.h); rays with a zero direction component take the compare ladder, which tests the reference explicitly.  Both
+    against the oracle, in every mode, on trees with one-child nodes and empty leaves, with and without a top-level tree."""
+    kind, seed, (w, h) = case
+    sc = _grid_scene(seed) if kind == "grid" else random_scene(seed)
+    b, n_int, n_empty = _pruned_buffers(sc, seed)
+    assert n_int > 3
+
+    def run(lib, sah, cull):
+        c = lib.create()
+        c.set_accel(sah)
+        c.set_scene(b["tris28"], b["meshes128"], b["nodes48"], b["leaf_tri_ids"], b["spheres96"], b["atmosphere80"])
+        c.load_camera(sc.cam)
+        c.resize(w, h)
+        c.set_cull(cull)
+        ids, ts = c.first_hit(1)
+        c.render(1, 3, 1, 2, 5, 0)
+        out = ids, ts, c.read_mean()
+        c.close()
+        return out
+
+    io, to, a = run(oracle_lib, False, 0)
+    assert (io >= 0).any()
+    for sah in (False, True):
+        for cull in (0, 1, 2):
+            ig, tg, g = run(hip_lib, sah, cull)
+            what = f"{kind} {seed} {w}x{h} sah={sah} cull={cull} ({n_empty} empty leaves)"
+            assert np.array_equal(io, ig), f"{what}: {(io != ig).sum()} first-hit ids differ"
+            assert np.array_equal(to.view(np.uint32), tg.view(np.uint32)), what
+            assert np.array_equal(a.view(np.uint32), g.view(np.uint32)), f"{what}: {(a != g).any(axis=2).sum()} pixels differ"
