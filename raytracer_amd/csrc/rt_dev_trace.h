@@ -12,14 +12,15 @@
 //
 // Data layout in HBM (built by rt_set_scene, refreshed by the prep kernels):
 //   tri_geo  4 x float4 per triangle SLOT (64 B, one half cache line):
-//              {A.xyz, N.x} {B.xyz, N.y} {C.xyz, N.z} {d, bits(rem), bits(rank), bits(flags)}
+//              {A.xyz, N.x} {B.xyz, N.y} {C.xyz, N.z} {d, bits(next), bits(rank), bits(flags)}
 //            slots are in traversal order of the reference (mesh ascending, depth-first,
 //            second child first, leaf order), so (a) every leaf and every subtree is one
 //            contiguous range, (b) the slot index is the rank that decides ties exactly as
 //            the reference's "first found wins" (strict <, :625) whatever order the kernel
 //            visits nodes in (rank = slot, stored explicitly so that a scene built with
 //            RT_ACCEL_SAH, whose slots follow another tree, resolves ties the same way).
-//            rem = triangles left in the leaf after this one;
+//            next = byte offset of the leaf's next slot in tri_geo, -1 after its last triangle (a lane walks a leaf by
+//            loading this word: no count, no add, no compare);
 //            flags = mesh index | RT_TFB_BIT (the mesh's transparentFromBehind).
 //   tri_hit  4 x float4 per slot (64 B), read only for the WINNER of a query - one scattered cache line per hit:
 //              {nA.xyz, bits(mesh)} {nB.xyz, lo.x} {nC.xyz, lo.y} {lo.z, hi.x, hi.y, hi.z}
@@ -29,7 +30,8 @@
 //            (991 k triangles: 80 MB of them) pays for.
 //   nodes    4 x float4 per INTERIOR node: both children's boxes and references
 //              {lo1.xyz, bits(ref1)} {hi1.xyz, bits(ref2)} {lo2.xyz, e1} {hi2.xyz, e2}
-//            ref >= 0: interior record index; ref < 0 and != RT_NONE: leaf, first slot = ~ref;
+//            ref >= 0: BYTE OFFSET of an interior record (index << 6); ref < 0 and != RT_NONE: leaf, byte offset of its
+//            first slot in tri_geo = ~ref (RT_REF_* below: no shift per step; records and slots are both 64 B);
 //            e = slack of the child's widened slab test (RT_ACCEL_SAH scenes; 0 otherwise).
 //   roots    2 x float4 per mesh: {lo.xyz, bits(ref)} {hi.xyz, e} of the mesh's root node.
 //   mats     the 80-byte std140 Material of every mesh, as uploaded.
@@ -68,6 +70,9 @@
 #define RT_PRIO_PATH 0
 #endif
 #define RT_NONE ((int)0x80000000)
+// child / root references as the device stores them (k_pack_nodes): byte offsets, see the layout above
+#define RT_REF_OF_RECORD(i) ((int)((uint32_t)(i) << 6))
+#define RT_REF_OF_LEAF(slot) (~(int)((uint32_t)(slot) << 6))
 #define RT_BLOCK 256
 #define RT_MISS_RANK 0x7fffffff
 #define RT_SPHERE_RANK (-(1 << 30))
@@ -295,10 +300,10 @@ __device__ __forceinline__ const MatDev* material_of(const DevScene& S, int idx)
 // yet visited) and leaf work (the triangle in progress / the leaf queue) at the same time, so
 // it can take part in whichever kind of step the wave votes for.
 struct Trav {
-    int cur;          // interior record to test next (>= 0), or RT_NONE
+    int cur;          // interior record to test next (its byte offset in nodes, >= 0), or RT_NONE
     int sp;           // node stack entries
     int lq;           // leaf queue entries
-    int k;            // triangle slot in progress, or -1
+    int k;            // triangle slot in progress (its byte offset in tri_geo), or -1
     uint32_t mask;    // mesh roots still to visit (scenes of up to 32 meshes; larger ones start at the top-level tree)
     float best_t;
     int best_rank;
@@ -566,27 +571,11 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             if (STATS && do_node) { sch.node_steps++; sch.node_lanes += cN; }
             if (do_node) {
                 if (can_node) {
-                    if (tv.cur == RT_NONE) {
-                        // ---- take up node work: a deferred far child, else the next mesh root ----
-                        if (tv.sp > 0) {
-                            tv.sp--;
-                            if (!DEEP || tv.sp < S.stack_depth) tv.cur = s_stack[tv.sp * RT_BLOCK];
-                            else                                    // a rare deep entry (see stack_ovf)
-                                tv.cur = a.stack_ovf[(size_t)(tv.sp - S.stack_depth) * a.ovf_lanes + (blockIdx.x * RT_BLOCK + threadIdx.x)];
-                        } else if (tv.mask) {
-                            const int b = __builtin_ctz(tv.mask);
-                            tv.mask &= tv.mask - 1;
-                            const int ref = __float_as_int(s_roots[2 * b].w);
-                            if (ref >= 0) tv.cur = ref;
-                            else {                                  // the mesh's root node is a leaf (:586)
-                                s_leaf[tv.lq * RT_BLOCK] = ref;
-                                if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = 0;   // distance 0: never culled
-                                tv.lq++;
-                            }
-                        }
-                    }
-                    if (tv.cur != RT_NONE) {                        // :562-584, both children of `cur`
-                        const float4* n = (const float4*)((const char*)S.nodes + ((uint32_t)tv.cur << 6));
+                    // A lane that can take a node step HOLDS a record: when a step leaves it without a child to go on with, it
+                    // takes the next one up at once (end of this block).  So "node work remains" (m_live) is just "a record is in
+                    // hand" - one compare per step where the step used to check the record, the stack and the root mask (-1.6 %).
+                    {                                               // :562-584, both children of `cur`
+                        const float4* n = (const float4*)((const char*)S.nodes + (uint32_t)tv.cur);
                         const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
                         const int ref1 = __float_as_int(n0.w), ref2 = __float_as_int(n1.w);
                         float t1a, t1b, t2a, t2b;
@@ -653,19 +642,31 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             tv.sp++;
                         }
                         tv.cur = in_mask(m_in) ? rn : (in_mask(m_if) ? rf : RT_NONE);
+                        // ---- no child to go on with: take up the next record NOW (a deferred far child, else the next mesh root),
+                        // so that between steps "node work remains" is simply "a record is in hand" ----
+                        if (tv.cur == RT_NONE) {
+                            if (tv.sp > 0) {
+                                tv.sp--;
+                                if (!DEEP || tv.sp < S.stack_depth) tv.cur = s_stack[tv.sp * RT_BLOCK];
+                                else                                    // a rare deep entry (see stack_ovf)
+                                    tv.cur = a.stack_ovf[(size_t)(tv.sp - S.stack_depth) * a.ovf_lanes + (blockIdx.x * RT_BLOCK + threadIdx.x)];
+                            } else if (tv.mask) {                       // (a root in the table is never a leaf: rt_set_scene wraps those)
+                                const int b = __builtin_ctz(tv.mask);
+                                tv.mask &= tv.mask - 1;
+                                tv.cur = __float_as_int(s_roots[2 * b].w);
+                            }
+                        }
                     }
                 }
-                // nothing in hand, nothing deferred, no root left: node work is over now, not
-                // one step later (saves one node step per ray)
-                m_live &= ~(bN & lane_mask(tv.cur == RT_NONE) & lane_mask(tv.sp == 0) & lane_mask(tv.mask == 0));
+                m_live &= ~(bN & lane_mask(tv.cur == RT_NONE));
             } else {
                 // triangle burst: stay on triangles while at least half of the lanes that were
                 // traversing at the vote still have leaf work (an upper bound of the lanes a node
                 // step could serve then outnumbers them and the full vote is taken again)
                 const int lim = cN + cT;
                 int cTn;
+                uint64_t m_leaf = bT;                                   // lanes with leaf work: the vote's mask, then each step's own
                 do {
-                    const uint64_t m_leaf = lane_mask(tv.k >= 0) | lane_mask(tv.lq > 0);
                     if (STATS) { sch.tri_steps++; sch.tri_lanes += __popcll(m_leaf); }
                     if (in_mask(m_leaf)) {
                         if (tv.k < 0) {                                 // take up the most recently found leaf
@@ -676,8 +677,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 tv.k = -1;
                         }
                         if (tv.k >= 0) {                                // one triangle of the leaf (:593-630)
-                            // 32-bit byte offset from a uniform base: one shift, no 64-bit address arithmetic
-                            const float4* g = (const float4*)((const char*)S.tri_geo + ((uint32_t)tv.k << 6));
+                            // tv.k is the slot's 32-bit byte offset from a uniform base: no shift, no 64-bit address arithmetic
+                            const float4* g = (const float4*)((const char*)S.tri_geo + (uint32_t)tv.k);
                             const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3];
                             // all rejects are folded into one predicate and the three edge tests run together:
                             // one divergent region instead of five nested ones (scalar-unit pressure)
@@ -706,15 +707,16 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 // REFERENCE's tree
                                 const uint64_t m_chk = SAH ? m_gated & lane_mask(inside) : 0;
                                 if (SAH && m_chk != 0) {
-                                    if (in_mask(m_chk)) inside = ref_leaf_box_passes(S, tv.k, org, inv);
+                                    if (in_mask(m_chk)) inside = ref_leaf_box_passes(S, (int)((uint32_t)tv.k >> 6), org, inv);
                                 }
                                 tv.best_t = inside ? t : tv.best_t;
                                 tv.best_rank = inside ? rank_k : tv.best_rank;
                             }
-                            tv.k = __float_as_int(g3.y) > 0 ? tv.k + 1 : -1;
+                            tv.k = __float_as_int(g3.y);                    // the leaf's next slot, or -1
                         }
                     }
-                    cTn = __popcll(lane_mask(tv.k >= 0) | lane_mask(tv.lq > 0));
+                    m_leaf = lane_mask(tv.k >= 0) | lane_mask(tv.lq > 0);
+                    cTn = __popcll(m_leaf);
                 } while (cTn > 0 && 8 * cTn >= a.burst8 * lim);
             }
         }
@@ -1009,9 +1011,11 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     int nearest;
                     tv.mask = root_mask<STATS, CULL>(__builtin_amdgcn_readfirstlane(PS.n_roots), s_roots, org, inv, tv.best_t, sah, cnt, nearest);
                     // the mesh whose root box the ray enters first is visited first (a hit there culls the others)
-                    if (nearest >= 0) {
-                        const int ref = __float_as_int(s_roots[2 * nearest].w);
-                        if (ref >= 0) { tv.cur = ref; tv.mask &= ~(1u << nearest); }
+                    // (entry distances of +inf / NaN leave `nearest` unset: then the first root of the mask; roots are interior records)
+                    if (tv.mask) {
+                        const int b = nearest >= 0 ? nearest : __builtin_ctz(tv.mask);
+                        tv.cur = __float_as_int(s_roots[2 * b].w);
+                        tv.mask &= ~(1u << b);
                     }
                 }
                 mode = M_TRAV;
@@ -1021,7 +1025,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
         // The wave is converged here: take the two lane masks anew, for the queries that have just started and (to the
         // same values: node work remains <=> a record in hand, a deferred one or a root left) for those still in flight.
         // A lane without a query keeps the 1/d of its last one; its bit in m_nonfinite is never looked at.
-        m_live = lane_mask(mode == M_TRAV) & (lane_mask(tv.cur != RT_NONE) | lane_mask(tv.sp > 0) | lane_mask(tv.mask != 0));
+        m_live = lane_mask(mode == M_TRAV) & lane_mask(tv.cur != RT_NONE);
         m_gated = SAH ? lane_mask(gated) : 0;
         m_nonfinite = ~(lane_mask(__builtin_isfinite(inv.x)) & lane_mask(__builtin_isfinite(inv.y)) & lane_mask(__builtin_isfinite(inv.z)));
     }

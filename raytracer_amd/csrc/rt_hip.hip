@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void k_pose(PoseArgs a) {
     g[1] = make_float4(B.x, B.y, B.z, N.y);
     g[2] = make_float4(C.x, C.y, C.z, N.z);
     const int flags = mesh | (a.mats[mesh].transparentFromBehind ? RT_TFB_BIT : 0);
-    g[3] = make_float4(d, __int_as_float(a.slot_rem[k]), __int_as_float(a.slot_rank[k]), __int_as_float(flags));
+    const int next = a.slot_rem[k] > 0 ? (int)((uint32_t)(k + 1) << 6) : -1;   // byte offset of the leaf's next slot (rt_dev_trace.h)
+    g[3] = make_float4(d, __int_as_float(next), __int_as_float(a.slot_rank[k]), __int_as_float(flags));
     // hit record (rt_dev_trace.h): normals + mesh; the box fields (.w of [1] and [2], all of [3]) belong to k_ref_leaf_boxes,
     // which runs after this kernel in every prep of an RT_ACCEL_SAH scene
     float4* o = a.nrm + 4 * (size_t)k;
@@ -133,8 +134,12 @@ __global__ __launch_bounds__(256) void k_refit_level(const VNode* vn, const int*
     nbox[2 * (size_t)v + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
 }
 
-// interior record r <- boxes of its children; PackInfo is static topology
+// interior record r <- boxes of its children; PackInfo is static topology (references as INDICES: >= 0 record, < 0 leaf with
+// first slot ~ref, RT_NONE absent; the device form is made by dev_ref when the records are packed)
 struct PackInfo { int c1, c2, ref1, ref2; };
+__host__ __device__ __forceinline__ int dev_ref(int ref) {
+    return ref == RT_NONE ? RT_NONE : ref >= 0 ? RT_REF_OF_RECORD(ref) : RT_REF_OF_LEAF(~ref);
+}
 
 // SAH structure: each box carries the slack of its widened slab test (rt_dev_trace.h,
 // sah_widened_hit): e2 = 2 * (2^-16 of its largest coordinate + 2^-20).  0 for the reference's
@@ -187,15 +192,15 @@ __global__ __launch_bounds__(256) void k_pack_nodes(const PackInfo* pi, int n_re
         float4 lo2 = a2 ? nbox[2 * (size_t)p.c2] : zn, hi2 = a2 ? nbox[2 * (size_t)p.c2 + 1] : zn;
         lo2.w = a1 ? box_slack(lo1, hi1, pad) : qn;
         hi2.w = a2 ? box_slack(lo2, hi2, pad) : qn;
-        lo1.w = __int_as_float(p.ref1);
-        hi1.w = __int_as_float(p.ref2);
+        lo1.w = __int_as_float(dev_ref(p.ref1));
+        hi1.w = __int_as_float(dev_ref(p.ref2));
         float4* o = nodes + 4 * (size_t)i;
         o[0] = lo1; o[1] = hi1; o[2] = lo2; o[3] = hi2;
     }
     if (i < n_meshes) {
         float4 lo = nbox[2 * (size_t)root_v[i]], hi = nbox[2 * (size_t)root_v[i] + 1];
         hi.w = box_slack(lo, hi, pad);
-        lo.w = __int_as_float(root_ref[i]);
+        lo.w = __int_as_float(dev_ref(root_ref[i]));
         roots[2 * i] = lo;
         roots[2 * i + 1] = hi;
     }
@@ -606,7 +611,7 @@ DevScene scene_view(const rt_ctx* c) {
     s.tri_geo = c->geo.p; s.tri_hit = c->nrm.p; s.nodes = c->nodes.p; s.roots = c->roots.p;
     s.mats = c->mats.p; s.spheres = c->spheres.p; s.rank_slot = c->rank_slot.p; s.slot_id = c->slot_id.p; s.n_meshes = c->n_meshes; s.n_roots = c->n_roots; s.n_spheres = c->n_spheres;
     s.stack_depth = c->stack_depth;
-    s.tlas_root = c->tlas_root;
+    s.tlas_root = c->tlas_root >= 0 ? dev_ref(c->tlas_root) : -1;
     s.rank_lds = rank_lds_entries(c);
     return s;
 }
@@ -967,6 +972,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
         max_depth = 0;
         const size_t visit_cap = 4 * (size_t)wn_count + 16;
         const int n_walk_roots = (int)wroot.size();
+        const bool wrap_leaf_roots = n_meshes <= c->tlas_above;
         root_v.assign(n_walk_roots, 0);
         root_ref.assign(n_walk_roots, RT_NONE);
         for (int j = 0; j < n_walk_roots; j++) {
@@ -1016,6 +1022,17 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
                 else { pack[cur.parent_rec].c2 = v; pack[cur.parent_rec].ref2 = ref; }
             }
         }
+        // A root of the root table that is a LEAF (a mesh of a few triangles) gets a record of its own: one child, the leaf, and
+        // one absent child.  k_trace can then rely on every root it takes from the table being an interior record (it takes the
+        // next record up when a node step ends, and "a record in hand" is all it keeps track of); the price is one node step for
+        // such a mesh.  Appended after the records of the walk, whose order the loop below relies on.  Not under a top-level
+        // tree: there a mesh root is a child of a tree node like any other.
+        if (wrap_leaf_roots)
+            for (int j = 0; j < n_walk_roots; j++)
+                if (root_ref[j] < 0 && root_ref[j] != RT_NONE) {
+                    pack.push_back({root_v[j], -1, root_ref[j], RT_NONE});
+                    root_ref[j] = (int)pack.size() - 1;
+                }
         // child visit indices for the refit (vnode.c1/c2), from the pack table
         int rec = 0;
         for (size_t v = 0; v < vnodes.size(); v++) {
