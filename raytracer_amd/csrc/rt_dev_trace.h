@@ -69,10 +69,13 @@
 #ifndef RT_PRIO_PATH
 #define RT_PRIO_PATH 0
 #endif
+// child / root references as the device stores them (k_pack_nodes): byte offsets, see the layout above.  ("No record" as -1, an
+// inline constant of the instruction set instead of a value that has to sit in a register: measured +-0, round 3.)
 #define RT_NONE ((int)0x80000000)
-// child / root references as the device stores them (k_pack_nodes): byte offsets, see the layout above
 #define RT_REF_OF_RECORD(i) ((int)((uint32_t)(i) << 6))
 #define RT_REF_OF_LEAF(slot) (~(int)((uint32_t)(slot) << 6))
+#define RT_LEAF_OFFSET(ref) (~(ref))
+#define RT_IDX_NONE ((int)0x80000000)      // host-side index form of a reference (PackInfo): absent
 #define RT_BLOCK 256
 #define RT_MISS_RANK 0x7fffffff
 #define RT_SPHERE_RANK (-(1 << 30))
@@ -255,6 +258,7 @@ enum { M_TRAV = 0, M_WAIT = 1, M_PATH = 2, M_DONE = 3 };
 #define RT_LQ_SAH 3
 #endif
 #define RT_LQ_OF(sah) ((sah) ? RT_LQ_SAH : RT_LQ)
+#define RT_LQ64_OF(sah, cull, deep) ((sah) && (cull) != 0 && !(deep))   // 8-byte leaf queue entries (see trace_pixels)
 #define RT_MIN_STACK_LDS 4         // node stack entries a lane always has in LDS
 #define RT_TFB_BIT 0x40000000      // tri_geo[3].w = mesh index | RT_TFB_BIT if the mesh is transparentFromBehind
 
@@ -508,9 +512,15 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     const int n_ent = S.stack_depth + LQ;
     // (the leaf queue comes FIRST in a column: the node stack then starts at a compile-time offset from the same base
     // register, where "stack first" needs a second base register per plane for a run-time stack depth)
+    // SAH + culling with the whole node stack in LDS: a queued leaf is ONE 8-byte entry (reference, entry distance as float32) -
+    // one address and one LDS instruction per push / take-up instead of two of each (-0.5 % on the bench frame); 1.5 KB more
+    // LDS per workgroup, which a scene that needs the DEEP instantiation rather spends on stack entries (dragon scene: +1.8 %
+    // with two entries fewer in LDS), so those keep the 4 + 2-byte planes.  rt_hip.hip::trace_lds_bytes is the other half.
+    constexpr bool LQ64 = RT_LQ64_OF(SAH, CULL, DEEP);
     int* s_leaf = (int*)(s_mem + n_root4 + RT_PC_F4) + threadIdx.x;
+    int2* s_leaf2 = (int2*)(s_mem + n_root4 + RT_PC_F4) + threadIdx.x;
     unsigned short* s_leaf_t = (unsigned short*)((int*)(s_mem + n_root4 + RT_PC_F4) + (size_t)n_ent * RT_BLOCK) + threadIdx.x;
-    int* s_stack = s_leaf + (size_t)LQ * RT_BLOCK;
+    int* s_stack = LQ64 ? (int*)(s_mem + n_root4 + RT_PC_F4) + (size_t)2 * LQ * RT_BLOCK + threadIdx.x : s_leaf + (size_t)LQ * RT_BLOCK;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -626,13 +636,19 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         const int rn = second_near ? ref2 : ref1, rf = second_near ? ref1 : ref2;
                         const float tn = second_near ? t2a : t1a, tf = second_near ? t1a : t2a;
                         if (in_mask(m_hf & m_lf)) {
-                            s_leaf[tv.lq * RT_BLOCK] = rf;
-                            if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tf);
+                            if (LQ64) s_leaf2[tv.lq * RT_BLOCK] = make_int2(rf, __float_as_int(tf));
+                            else {
+                                s_leaf[tv.lq * RT_BLOCK] = rf;
+                                if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tf);
+                            }
                             tv.lq++;
                         }
                         if (in_mask(m_hn & m_ln)) {
-                            s_leaf[tv.lq * RT_BLOCK] = rn;
-                            if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tn);
+                            if (LQ64) s_leaf2[tv.lq * RT_BLOCK] = make_int2(rn, __float_as_int(tn));
+                            else {
+                                s_leaf[tv.lq * RT_BLOCK] = rn;
+                                if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tn);
+                            }
                             tv.lq++;
                         }
                         const uint64_t m_in = m_hn & ~m_ln, m_if = m_hf & ~m_lf;
@@ -671,10 +687,16 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     if (in_mask(m_leaf)) {
                         if (tv.k < 0) {                                 // take up the most recently found leaf
                             tv.lq--;
-                            const int ref = s_leaf[tv.lq * RT_BLOCK];
-                            tv.k = ~ref;
-                            if (CULL && unpack_dist(s_leaf_t[tv.lq * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS)
-                                tv.k = -1;
+                            if (LQ64) {
+                                const int2 e = s_leaf2[tv.lq * RT_BLOCK];
+                                tv.k = RT_LEAF_OFFSET(e.x);
+                                if (__int_as_float(e.y) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS) tv.k = -1;
+                            } else {
+                                const int ref = s_leaf[tv.lq * RT_BLOCK];
+                                tv.k = RT_LEAF_OFFSET(ref);
+                                if (CULL && unpack_dist(s_leaf_t[tv.lq * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS)
+                                    tv.k = -1;
+                            }
                         }
                         if (tv.k >= 0) {                                // one triangle of the leaf (:593-630)
                             // tv.k is the slot's 32-bit byte offset from a uniform base: no shift, no 64-bit address arithmetic

@@ -135,10 +135,10 @@ __global__ __launch_bounds__(256) void k_refit_level(const VNode* vn, const int*
 }
 
 // interior record r <- boxes of its children; PackInfo is static topology (references as INDICES: >= 0 record, < 0 leaf with
-// first slot ~ref, RT_NONE absent; the device form is made by dev_ref when the records are packed)
+// first slot ~ref, RT_IDX_NONE absent; the device form is made by dev_ref when the records are packed)
 struct PackInfo { int c1, c2, ref1, ref2; };
 __host__ __device__ __forceinline__ int dev_ref(int ref) {
-    return ref == RT_NONE ? RT_NONE : ref >= 0 ? RT_REF_OF_RECORD(ref) : RT_REF_OF_LEAF(~ref);
+    return ref == RT_IDX_NONE ? RT_NONE : ref >= 0 ? RT_REF_OF_RECORD(ref) : RT_REF_OF_LEAF(~ref);
 }
 
 // SAH structure: each box carries the slack of its widened slab test (rt_dev_trace.h,
@@ -180,14 +180,14 @@ __global__ __launch_bounds__(256) void k_pack_nodes(const PackInfo* pi, int n_re
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_rec) {
         PackInfo p = pi[i];
-        // An absent child (ref RT_NONE) gets an all-NaN box and a NaN slack: in the min/max form of the slab test (rays with finite
+        // An absent child (ref RT_IDX_NONE) gets an all-NaN box and a NaN slack: in the min/max form of the slab test (rays with finite
         // 1/d) every slab value and so the interval is NaN, and "NaN <= x" is false - it can never be entered, whatever the ray,
         // which is what lets k_trace drop the compare of the reference there.  (No finite or infinite box has that property: the
         // min/max form is symmetric in lo and hi, so an inverted box is the whole line.)  An EMPTY leaf that the walk kept as a
-        // child (c >= 0, no triangles) has ref RT_NONE too: same treatment, whatever the refit wrote for it.
+        // child (c >= 0, no triangles) has ref RT_IDX_NONE too: same treatment, whatever the refit wrote for it.
         const float qn = __int_as_float(0x7fc00000);
         const float4 zn = make_float4(qn, qn, qn, qn);
-        const bool a1 = p.c1 >= 0 && p.ref1 != RT_NONE, a2 = p.c2 >= 0 && p.ref2 != RT_NONE;
+        const bool a1 = p.c1 >= 0 && p.ref1 != RT_IDX_NONE, a2 = p.c2 >= 0 && p.ref2 != RT_IDX_NONE;
         float4 lo1 = a1 ? nbox[2 * (size_t)p.c1] : zn, hi1 = a1 ? nbox[2 * (size_t)p.c1 + 1] : zn;
         float4 lo2 = a2 ? nbox[2 * (size_t)p.c2] : zn, hi2 = a2 ? nbox[2 * (size_t)p.c2 + 1] : zn;
         lo2.w = a1 ? box_slack(lo1, hi1, pad) : qn;
@@ -344,7 +344,7 @@ void build_tlas(int n_meshes, const float* box_lo, const float* box_hi, const Tl
             vnodes.push_back({-1, -1, 0, 0});
             vdepth.push_back(job.depth);
             ref = (int)pack.size();
-            pack.push_back({-1, -1, RT_NONE, RT_NONE});
+            pack.push_back({-1, -1, RT_IDX_NONE, RT_IDX_NONE});
             tlas_height = std::max(tlas_height, job.depth + 1);
             vnode_of_rec.push_back({ref, v});
             if (job.sah_node >= 0) {
@@ -661,9 +661,10 @@ int rank_lds_entries(const rt_ctx* c) {
     return (c->scene_is_sah && c->tlas_root < 0 && c->n_slots <= 2048) ? c->n_slots : 0;
 }
 
-size_t trace_lds_bytes(const rt_ctx* c, int cap, bool cull, bool sah) {
+size_t trace_lds_bytes(const rt_ctx* c, int cap, bool cull, bool sah, bool deep) {
     const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_roots + 5 * c->n_meshes) + (size_t)(rank_lds_entries(c) + 3) / 4 + RT_PC_F4) * sizeof(float4);   // roots, materials, rank table, arguments
     const size_t lq = RT_LQ_OF(sah);
+    if (RT_LQ64_OF(sah, cull, deep)) return fixed + ((size_t)cap * 4 + lq * 8) * RT_BLOCK;      // 8-byte leaf queue entries (rt_dev_trace.h)
     return fixed + ((size_t)cap + lq) * RT_BLOCK * 4 + (cull ? lq * RT_BLOCK * 2 : 0);
 }
 
@@ -672,21 +673,21 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     if (c->blocks_per_cu[key] <= 0) {
         int nb = 0, nb_best = 0;
         for (;;) {
-            HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS>, RT_BLOCK, trace_lds_bytes(c, cap, CULL, SAH)));
+            HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS>, RT_BLOCK, trace_lds_bytes(c, cap, CULL, SAH, DEEP)));
             if (!DEEP || nb >= RT_WAVES || cap <= RT_MIN_STACK_LDS || c->stack_lds_force > 0) break;
             // lds_stack_entries guessed the allocation granule wrong, or registers are the limit
             if (nb_best == 0)
-                HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_best, k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS>, RT_BLOCK, trace_lds_bytes(c, RT_MIN_STACK_LDS, CULL, SAH)));
+                HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_best, k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS>, RT_BLOCK, trace_lds_bytes(c, RT_MIN_STACK_LDS, CULL, SAH, DEEP)));
             if (nb >= nb_best) break;
             cap--;
         }
-        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (%d roots, %d meshes)", trace_lds_bytes(c, cap, CULL, SAH), c->n_roots, c->n_meshes);
+        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (%d roots, %d meshes)", trace_lds_bytes(c, cap, CULL, SAH, DEEP), c->n_roots, c->n_meshes);
         c->blocks_per_cu[key] = nb;
         c->stack_lds[key] = cap;
-        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] k_trace variant %d: %d of %d node stack entries in LDS, %zu bytes of LDS, %d workgroups per CU\n", key, cap, c->stack_depth, trace_lds_bytes(c, cap, CULL, SAH), nb);
+        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] k_trace variant %d: %d of %d node stack entries in LDS, %zu bytes of LDS, %d workgroups per CU\n", key, cap, c->stack_depth, trace_lds_bytes(c, cap, CULL, SAH, DEEP), nb);
     }
     cap = c->stack_lds[key];
-    const size_t lds = trace_lds_bytes(c, cap, CULL, SAH);
+    const size_t lds = trace_lds_bytes(c, cap, CULL, SAH, DEEP);
     // every wave takes whole chunks: no point in more waves than chunks
     unsigned grid = std::max(1u, (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_jobs + 3) / 4));
     TraceArgs b = a;
@@ -734,13 +735,16 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
 }
 
 // node stack entries kept in LDS: all of them if RT_WAVES workgroups per CU still fit, else as many as do
-int lds_stack_entries(const rt_ctx* c) {
+// (*deep_layout: the DEEP instantiation is to be used even if every entry fits - its LDS layout is the smaller one, see RT_LQ64_OF)
+int lds_stack_entries(const rt_ctx* c, bool* deep_layout) {
+    *deep_layout = false;
     if (c->stack_lds_force > 0) return std::min(c->stack_depth, c->stack_lds_force);
     // LDS is handed out in 1280-byte granules on gfx950 (160 KB / 128): budget per workgroup rounded down to that
     const size_t budget = (c->lds_per_cu / RT_WAVES) / 1280 * 1280;
-    if (trace_lds_bytes(c, c->stack_depth, c->cull, c->scene_is_sah) <= budget) return c->stack_depth;
-    const size_t base = trace_lds_bytes(c, 0, c->cull, c->scene_is_sah);
+    if (trace_lds_bytes(c, c->stack_depth, c->cull, c->scene_is_sah, false) <= budget) return c->stack_depth;   // whole stack in LDS
+    const size_t base = trace_lds_bytes(c, 0, c->cull, c->scene_is_sah, true);
     const int fit = (int)((budget > base ? budget - base : 0) / ((size_t)RT_BLOCK * 4));
+    *deep_layout = true;
     return std::max(RT_MIN_STACK_LDS, std::min(c->stack_depth, fit));
 }
 
@@ -755,8 +759,8 @@ int launch_mats(rt_ctx* c, const TraceArgs& a, int key, int cap) {
 }
 
 template <bool STATS, int CULL, bool FIRST>
-int launch_accel(rt_ctx* c, const TraceArgs& a, int key, int cap) {
-    const bool deep = cap < c->stack_depth;
+int launch_accel(rt_ctx* c, const TraceArgs& a, int key, int cap, bool deep_layout) {
+    const bool deep = cap < c->stack_depth || deep_layout;
     if (c->scene_is_sah) return deep ? launch_mats<STATS, CULL, FIRST, true, true>(c, a, key, cap) : launch_mats<STATS, CULL, FIRST, true, false>(c, a, key, cap);
     return deep ? launch_mats<STATS, CULL, FIRST, false, true>(c, a, key, cap) : launch_mats<STATS, CULL, FIRST, false, false>(c, a, key, cap);
 }
@@ -765,20 +769,21 @@ int launch_trace(rt_ctx* c, const TraceArgs& a, bool first_hit) {
     // the instantiation is fixed by (stats, cull mode, first hit) and, per scene, by (structure, deep):
     // 12 cache slots (of 16) for the occupancy of the scene in place
     const int key = (c->stats_on ? 8 : 0) | (c->cull << 1) | (first_hit ? 1 : 0);
-    const int cap = lds_stack_entries(c);
+    bool dl = false;
+    const int cap = lds_stack_entries(c, &dl);
     switch (key) {
-    case 0: return launch_accel<false, 0, false>(c, a, key, cap);
-    case 1: return launch_accel<false, 0, true>(c, a, key, cap);
-    case 2: return launch_accel<false, 1, false>(c, a, key, cap);
-    case 3: return launch_accel<false, 1, true>(c, a, key, cap);
-    case 4: return launch_accel<false, 2, false>(c, a, key, cap);
-    case 5: return launch_accel<false, 2, true>(c, a, key, cap);
-    case 8: return launch_accel<true, 0, false>(c, a, key, cap);
-    case 9: return launch_accel<true, 0, true>(c, a, key, cap);
-    case 10: return launch_accel<true, 1, false>(c, a, key, cap);
-    case 11: return launch_accel<true, 1, true>(c, a, key, cap);
-    case 12: return launch_accel<true, 2, false>(c, a, key, cap);
-    case 13: return launch_accel<true, 2, true>(c, a, key, cap);
+    case 0: return launch_accel<false, 0, false>(c, a, key, cap, dl);
+    case 1: return launch_accel<false, 0, true>(c, a, key, cap, dl);
+    case 2: return launch_accel<false, 1, false>(c, a, key, cap, dl);
+    case 3: return launch_accel<false, 1, true>(c, a, key, cap, dl);
+    case 4: return launch_accel<false, 2, false>(c, a, key, cap, dl);
+    case 5: return launch_accel<false, 2, true>(c, a, key, cap, dl);
+    case 8: return launch_accel<true, 0, false>(c, a, key, cap, dl);
+    case 9: return launch_accel<true, 0, true>(c, a, key, cap, dl);
+    case 10: return launch_accel<true, 1, false>(c, a, key, cap, dl);
+    case 11: return launch_accel<true, 1, true>(c, a, key, cap, dl);
+    case 12: return launch_accel<true, 2, false>(c, a, key, cap, dl);
+    case 13: return launch_accel<true, 2, true>(c, a, key, cap, dl);
     default: return fail(c, RT_E_STATE, "no k_trace instantiation for key %d", key);
     }
 }
@@ -974,7 +979,7 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
         const int n_walk_roots = (int)wroot.size();
         const bool wrap_leaf_roots = n_meshes <= c->tlas_above;
         root_v.assign(n_walk_roots, 0);
-        root_ref.assign(n_walk_roots, RT_NONE);
+        root_ref.assign(n_walk_roots, RT_IDX_NONE);
         for (int j = 0; j < n_walk_roots; j++) {
             std::vector<Visit> st;
             st.push_back({wroot[j], 0, -1, 0});
@@ -1009,10 +1014,10 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
                         slot_rem.push_back(n.cnt - 1 - i);
                         slot_id.push_back(t.triId);
                     }
-                    ref = n.cnt > 0 ? ~vnodes[v].start : RT_NONE;     // an empty leaf contributes nothing
+                    ref = n.cnt > 0 ? ~vnodes[v].start : RT_IDX_NONE;     // an empty leaf contributes nothing
                 } else {
                     ref = (int)pack.size();
-                    pack.push_back({-1, -1, RT_NONE, RT_NONE});
+                    pack.push_back({-1, -1, RT_IDX_NONE, RT_IDX_NONE});
                     // push first child first so that the second child is visited first
                     if (n.c1 >= 0) st.push_back({n.c1, cur.depth + 1, ref, 1});
                     if (n.c2 >= 0) st.push_back({n.c2, cur.depth + 1, ref, 2});
@@ -1029,8 +1034,8 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
         // tree: there a mesh root is a child of a tree node like any other.
         if (wrap_leaf_roots)
             for (int j = 0; j < n_walk_roots; j++)
-                if (root_ref[j] < 0 && root_ref[j] != RT_NONE) {
-                    pack.push_back({root_v[j], -1, root_ref[j], RT_NONE});
+                if (root_ref[j] < 0 && root_ref[j] != RT_IDX_NONE) {
+                    pack.push_back({root_v[j], -1, root_ref[j], RT_IDX_NONE});
                     root_ref[j] = (int)pack.size() - 1;
                 }
         // child visit indices for the refit (vnode.c1/c2), from the pack table

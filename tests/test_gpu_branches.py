@@ -81,8 +81,16 @@ def test_deep_stack_entries_in_global_memory(hip_lib, monkeypatch):
             assert b[4]["stack_entries_lds"] == n < b[4]["stack_entries"]                                     # the switch did switch
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
             assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
-            for k in ("rays", "box_tests", "tri_tests", "shaded_hits"):
+            for k in ("rays", "shaded_hits"):
                 assert a[3][k] == b[3][k], (sah, cull, n, k)
+            for k in ("box_tests", "tri_tests"):
+                # the exact mode opens the same boxes whatever the schedule; with culling WHICH boxes are still worth opening
+                # depends on when a lane learns its best hit, and the two layouts keep a queued leaf's entry distance at
+                # different precision (float32 in the 8-byte entries of the all-LDS layout, 16 bits otherwise: RT_LQ64_OF)
+                if not cull:
+                    assert a[3][k] == b[3][k], (sah, cull, n, k)
+                else:
+                    assert abs(a[3][k] - b[3][k]) <= 1e-2 * a[3][k], (sah, cull, n, k)   # (measured: 0.002 % of the box tests, 0.26 % of the triangle tests)
 
 
 @pytest.mark.gpu
