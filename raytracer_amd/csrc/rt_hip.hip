@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rt_hip.h"
@@ -1629,11 +1630,10 @@ int rt_get_stats(rt_ctx* c, rt_stats_t* o) {
 namespace {
 typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*nccl_errstr_fn)(int);
-struct RcclApi { nccl_allreduce_fn allreduce = nullptr; nccl_errstr_fn errstr = nullptr; bool tried = false; char from[256] = {0}; };
+struct RcclApi { nccl_allreduce_fn allreduce = nullptr; nccl_errstr_fn errstr = nullptr; char from[256] = {0}; };
 RcclApi g_rccl;
-void load_rccl() {
-    if (g_rccl.tried) return;
-    g_rccl.tried = true;
+std::once_flag g_rccl_once;           // contexts of several host threads may make their first call at the same time
+void load_rccl_once() {
     void* h = nullptr;
     const char* names[] = {"librccl.so.1", "librccl.so"};
     if (const char* e = getenv("RT_RCCL_LIB")) {
@@ -1652,6 +1652,7 @@ void load_rccl() {
     g_rccl.allreduce = (nccl_allreduce_fn)dlsym(h, "ncclAllReduce");
     g_rccl.errstr = (nccl_errstr_fn)dlsym(h, "ncclGetErrorString");
 }
+void load_rccl() { std::call_once(g_rccl_once, load_rccl_once); }
 }  // namespace
 
 int rt_allreduce_sum(rt_ctx* c, void* nccl_comm, uint64_t total_passes) {
