@@ -190,7 +190,7 @@ __device__ __forceinline__ bool culled(float tmin, float tmax, float best_t) {
 // by e|1/d_a| <= e max|1/d|), ~100 x the rounding of the slab and edge arithmetic, so a ray whose
 // triangle test can pass always reaches the triangle.  The unwidened [tmin, tmax] still drives
 // the culling rules and the near-first order.  Which triangles COUNT is decided by the
-// reference's own leaf box (tri_box, see the path block).
+// reference's own leaf box (in the hit record, see the path block).
 __device__ __forceinline__ float sah_slack(v3 o, v3 inv) {
     return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(inv.x), __builtin_fabsf(inv.y)), __builtin_fabsf(inv.z));
 }
