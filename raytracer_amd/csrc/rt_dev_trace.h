@@ -216,6 +216,14 @@ __device__ __forceinline__ bool sah_box_test_any(v3 o, v3 inv, float4 lo, float4
 __device__ __forceinline__ uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ __forceinline__ bool in_mask(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+// 2 m + b as ONE vector instruction (add with carry-in from the lane mask of b); the compiler's own form is select + shift-or
+__device__ __forceinline__ uint32_t shl1_add(uint32_t m, uint64_t lanes_of_b) {
+    uint32_t r;
+    uint64_t carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(m), "s"(lanes_of_b));
+    return r;
+}
+
 // Entry distance of a queued leaf, kept in 16 bits (LDS is what limits occupancy here): the
 // top half of the binary32 pattern.  Truncation rounds a positive distance down, so the re-check
 // when the leaf is taken up can only cull less than the full value would; a negative distance
@@ -320,38 +328,44 @@ struct Trav {
 template <bool STATS, int CULL, bool FINITE>
 __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn, v3 org, v3 inv, float best_t, bool sah, Counters& cnt, int& nearest) {
     uint32_t mask = 0;
-    float near_t = __builtin_inff();      // (an entry distance of +inf or NaN leaves `nearest` unset: the order is a heuristic only)
-    nearest = -1;
-    const float mi = sah_slack(org, inv), mo = sah_org(org);
+    // Roots are walked from the last to the first so that the mask is built as mask + mask + take (one add-with-carry instead of
+    // select + or); "<=" against FLT_MAX then names the same root as "<" against +inf did walking upwards: the FIRST of the
+    // nearest ones, none for an entry distance of +inf or NaN (the order is a heuristic only, but the oracle mirrors it for
+    // its counters).
+    float near_t = 0x1.fffffep127f;
+    const float mi = sah_slack(org, inv), mo = sah_org(org), beyond = fma_(best_t, RT_CULL_REL, best_t) + RT_CULL_ABS;
     // One box per trip, not unrolled: the kernel is issue bound, so overlapping the LDS latency
     // of several boxes buys nothing, while two or three boxes in flight cost spilled registers
     // (0.8 GB of scratch writes per frame, measured).
-    constexpr int NB = 1;
+    // the root's LDS address in a VECTOR register (the empty asm hides that it is uniform): address of the reads and value of
+    // the `nearest` select at once - as a scalar it is copied to a vector register twice per trip
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) f4v* lds_f4;
+    const uint32_t base = (uint32_t)(uintptr_t)(lds_f4)s_roots;
+    uint32_t at = base + (uint32_t)(jn - 1) * 32u, near_at = base - 32u;
+    asm volatile("" : "+v"(at));
 #pragma nounroll
-    for (int b0 = 0; b0 < jn; b0 += NB) {
-        float4 lo[NB], hi[NB];
-#pragma unroll
-        for (int u = 0; u < NB; u++) {
-            const int j = min(b0 + u, jn - 1);
-            lo[u] = s_roots[2 * j];
-            hi[u] = s_roots[2 * j + 1];
-        }
-#pragma unroll
-        for (int u = 0; u < NB; u++) {
-            float ta, tb;
-            bool h;
-            if (!sah) h = FINITE ? box_test_finite(org, inv, lo[u], hi[u], ta, tb) : box_test(org, inv, lo[u], hi[u], ta, tb);
-            else if (FINITE) { box_test_finite(org, inv, lo[u], hi[u], ta, tb); h = sah_widened_hit(ta, tb, hi[u].w, mo, mi); }
-            else h = sah_box_test_any(org, inv, lo[u], hi[u], hi[u].w, mo, ta, tb);
-            const bool real = __float_as_int(lo[u].w) != RT_NONE && b0 + u < jn;
-            const bool take = real && h && !culled<CULL>(ta, tb, best_t);
-            if (STATS) cnt.box += real;
-            mask |= take ? (1u << (b0 + u)) : 0u;
-            const bool nearer = take && ta < near_t;
-            nearest = nearer ? b0 + u : nearest;
-            near_t = nearer ? ta : near_t;
-        }
+    for (int j = jn - 1; j >= 0; j--) {
+        const f4v lo_ = *(lds_f4)(uintptr_t)at, hi_ = *(lds_f4)(uintptr_t)(at + 16);
+        const float4 lo = make_float4(lo_.x, lo_.y, lo_.z, lo_.w), hi = make_float4(hi_.x, hi_.y, hi_.z, hi_.w);
+        float ta, tb;
+        uint64_t m_take;
+        if (!sah) m_take = lane_mask(FINITE ? box_test_finite(org, inv, lo, hi, ta, tb) : box_test(org, inv, lo, hi, ta, tb));
+        else if (FINITE) { box_test_finite(org, inv, lo, hi, ta, tb); m_take = lane_mask(sah_widened_hit(ta, tb, hi.w, mo, mi)); }
+        else m_take = lane_mask(sah_box_test_any(org, inv, lo, hi, hi.w, mo, ta, tb));
+        // a mesh without triangles: its box is all NaN (k_pack_nodes), which the min/max form can never enter; the ladder can
+        const bool real = (FINITE && !STATS) || __float_as_int(lo.w) != RT_NONE;
+        if (!(FINITE && !STATS)) m_take &= lane_mask(real);
+        if (CULL == 1) m_take &= lane_mask(!(tb < RT_CULL_BEHIND));
+        if (CULL) m_take &= lane_mask(!(ta > beyond));
+        if (STATS) cnt.box += real;
+        mask = shl1_add(mask, m_take);
+        const bool nearer = in_mask(m_take & lane_mask(ta <= near_t));
+        near_at = nearer ? at : near_at;
+        near_t = nearer ? ta : near_t;
+        at -= 32;
     }
+    nearest = (int)(near_at - base) >> 5;
     return mask;
 }
 

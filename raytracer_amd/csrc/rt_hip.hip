@@ -201,6 +201,10 @@ __global__ __launch_bounds__(256) void k_pack_nodes(const PackInfo* pi, int n_re
     if (i < n_meshes) {
         float4 lo = nbox[2 * (size_t)root_v[i]], hi = nbox[2 * (size_t)root_v[i] + 1];
         hi.w = box_slack(lo, hi, pad);
+        if (root_ref[i] == RT_IDX_NONE) {         // a mesh without triangles: a box no ray with finite 1/d can enter (see above)
+            const float qn = __int_as_float(0x7fc00000);
+            lo = hi = make_float4(qn, qn, qn, qn);
+        }
         lo.w = __int_as_float(dev_ref(root_ref[i]));
         roots[2 * i] = lo;
         roots[2 * i + 1] = hi;

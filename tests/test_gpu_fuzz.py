@@ -283,7 +283,7 @@ def test_set_cull_rejects_unknown_modes(hip_lib):
     c.close()
 
 
-def _pruned_buffers(sc, seed):
+def _pruned_buffers(sc, seed, empty_mesh=None):
     """The scene's upload buffers with nodes the reference's builder never makes but its shader handles (:562-584): interior
     nodes that lost one child (childId = -1) and leaves emptied to zero triangles - what becomes RT_NONE in the device records."""
     from raytracer_amd.scripts import functions as Fn
@@ -298,20 +298,26 @@ def _pruned_buffers(sc, seed):
     leaves = np.flatnonzero((nodes["childId1"] < 0) & (nodes["childId2"] < 0))
     for i in leaves[r.random(len(leaves)) < 0.1]:
         nodes[i]["childObjCount"] = 0
+    if empty_mesh is not None:
+        # a whole mesh emptied: its root becomes a leaf without triangles (an all-NaN root box on the device)
+        root = int(b["meshes128"]["node0Id"][empty_mesh % len(b["meshes128"])])
+        nodes[root]["childId1"] = nodes[root]["childId2"] = -1
+        nodes[root]["childObjCount"] = nodes[root]["childObjOffset"] = 0
     b["nodes48"] = nodes
     return b, int(len(interior)), int((nodes["childObjCount"][leaves] == 0).sum())
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [("grid", 0, (1, 129)), ("grid", 1, (129, 1)), ("grid", 2, (48, 27)), ("random", 3, (64, 36)),
-                                  ("random", 5, (64, 36)), ("random", 11, (64, 36))])
+                                  ("random", 5, (64, 36)), ("random", 11, (64, 36)), ("random", 3, (64, 36), 0), ("random", 5, (64, 36), 1),
+                                  ("random", 11, (64, 36), 2), ("grid", 2, (48, 27), 0)])
 def test_one_child_nodes_and_empty_leaves(oracle_lib, hip_lib, case):
     """Absent children carry NaN boxes on the device and the min/max slab test alone keeps rays out of them (k_pack_nodes,
     rt_dev_trace.h); rays with a zero direction component take the compare ladder, which tests the reference explicitly.  Both
     against the oracle, in every mode, on trees with one-child nodes and empty leaves, with and without a top-level tree."""
-    kind, seed, (w, h) = case
+    kind, seed, (w, h) = case[:3]
     sc = _grid_scene(seed) if kind == "grid" else random_scene(seed)
-    b, n_int, n_empty = _pruned_buffers(sc, seed)
+    b, n_int, n_empty = _pruned_buffers(sc, seed, case[3] if len(case) > 3 else None)
     assert n_int > 3
 
     def run(lib, sah, cull):
