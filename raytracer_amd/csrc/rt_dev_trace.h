@@ -372,7 +372,7 @@ __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn
 template <bool STATS, int CULL>
 __device__ __forceinline__ uint32_t root_mask(int jn, const float4* s_roots, v3 org, v3 inv, float best_t, bool sah, Counters& cnt, int& nearest) {
     // wave-uniform choice of the slab-test form (see box_test_finite)
-    const bool all_finite = __ballot(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0;
+    const bool all_finite = lane_mask(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0;
     return all_finite ? root_mask_loop<STATS, CULL, true>(s_roots, jn, org, inv, best_t, sah, cnt, nearest)
                       : root_mask_loop<STATS, CULL, false>(s_roots, jn, org, inv, best_t, sah, cnt, nearest);
 }
@@ -580,6 +580,11 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     // 1/d has a non-finite component (the query takes the reference's compare ladder instead of the min/max form).
     uint64_t m_live = 0, m_nonfinite = 0;
     uint64_t m_gated = 0;      // SAH: lanes whose query in flight is a repeat with the reference-leaf-box gate on every hit (`gated`)
+    // `mode` as the traversal loop sees it, as lane masks taken where the path block ends: lanes with a query in flight, lanes
+    // waiting for the path block.  A lane whose query finishes inside the loop is marked in m_fin (scalar logic on masks the
+    // vote computes anyway); its `mode` register is brought up to date once, when the loop is left - a compare and a select
+    // fewer in every trip of the vote.
+    uint64_t m_trav = 0, m_path = ~0ull, m_fin = 0;
 
     while (true) {
         // =============== traversal phase: node steps / triangle steps chosen by vote ===============
@@ -587,10 +592,10 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             const uint64_t bT = lane_mask(tv.k >= 0) | lane_mask(tv.lq > 0);           // has leaf work
             const uint64_t bN = m_live & lane_mask(tv.lq <= LQ - 2);                    // can take a node step
             const bool can_node = in_mask(bN);
-            if (in_mask(lane_mask(mode == M_TRAV) & ~bT & ~m_live)) mode = M_PATH;      // the query is finished
+            m_fin = m_trav & ~bT & ~m_live;                                             // the query is finished
             const int cN = __popcll(bN), cT = __popcll(bT), cAny = __popcll(bN | bT);
             if (cAny == 0) break;
-            if (cAny < a.refill_below && __ballot(mode == M_PATH) != 0) break;
+            if (cAny < a.refill_below && (m_fin | m_path) != 0) break;
             const bool do_node = cT == 0 || (cN > 0 && cN + a.node_bias > cT);   // never a step without lanes
             if (STATS && do_node) { sch.node_steps++; sch.node_lanes += cN; }
             if (do_node) {
@@ -756,11 +761,12 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 } while (cTn > 0 && 8 * cTn >= a.burst8 * lim);
             }
         }
-        if (__ballot(mode == M_PATH) == 0) break;                  // every lane is M_DONE (a lane in M_WAIT implies samples in flight, i.e. lanes that traverse)
+        if (in_mask(m_fin)) mode = M_PATH;
+        if (lane_mask(mode == M_PATH) == 0) break;                  // every lane is M_DONE (a lane in M_WAIT implies samples in flight, i.e. lanes that traverse)
 
         // =============== path phase: shade the finished query, start the next one ===============
         __builtin_amdgcn_s_setprio(RT_PRIO_PATH);
-        if (STATS) { sch.path_steps++; sch.path_lanes += __popcll(__ballot(mode == M_PATH)); }
+        if (STATS) { sch.path_steps++; sch.path_lanes += __popcll(lane_mask(mode == M_PATH)); }
         bool need = mode == M_WAIT, start = false, redo = false, completed = false;
         if (mode == M_PATH) {
             if (!fresh) {
@@ -804,9 +810,12 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
                         const v3 N = V3(g0.w, g1.w, g2.w);
                         backside = dot3(N, dir) > 0.0f;
-                        const float area = length3(N) / 2.0f;
-                        const float w = length3(cross3(B - A, hit_point - A)) / 2.0f / area;
-                        const float u = length3(cross3(C - B, hit_point - B)) / 2.0f / area;
+                        // (:364-379 divide half the cross products' lengths by the triangle's area, itself half a length: the halvings
+                        // are exact - a length is 0 or >= sqrt of the smallest subnormal, ~3.7e-23 - so the quotient of the halves is
+                        // the quotient of the lengths, same rounding; three multiplies fewer)
+                        const float len_n = length3(N);
+                        const float w = length3(cross3(B - A, hit_point - A)) / len_n;
+                        const float u = length3(cross3(C - B, hit_point - B)) / len_n;
                         const float v = 1.0f - u - w;
                         const float4* nn = PS.tri_hit + 4 * (size_t)slot;
                         const float4 na = nn[0], nb = nn[1], nc = nn[2];
@@ -921,14 +930,14 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             need = fresh && !have;
         }
         if (!FIRST_HIT) {                                          // samples finished in this block, per job slot (wave-uniform)
-            const uint64_t c0 = __ballot(completed && elem < P.job_cap), c1 = __ballot(completed && elem >= P.job_cap);
+            const uint64_t c0 = lane_mask(completed && elem < P.job_cap), c1 = lane_mask(completed && elem >= P.job_cap);
             if (lane == 0) {
                 if (c0) wj->done[0] = (uint16_t)(wj->done[0] + __popcll(c0));
                 if (c1) wj->done[1] = (uint16_t)(wj->done[1] + __popcll(c1));
             }
         }
         // ---- hand out samples: wave-uniform code, reached by every lane of the wave ----
-        for (uint64_t nm = __ballot(need); nm != 0; nm = __ballot(need)) {
+        for (uint64_t nm = lane_mask(need); nm != 0; nm = lane_mask(need)) {
             if (w_left == 0) {                                     // the job in hand is handed out completely
                 int free_slot = 0;
                 if (!FIRST_HIT) {
@@ -1061,7 +1070,9 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
         // The wave is converged here: take the two lane masks anew, for the queries that have just started and (to the
         // same values: node work remains <=> a record in hand, a deferred one or a root left) for those still in flight.
         // A lane without a query keeps the 1/d of its last one; its bit in m_nonfinite is never looked at.
-        m_live = lane_mask(mode == M_TRAV) & lane_mask(tv.cur != RT_NONE);
+        m_trav = lane_mask(mode == M_TRAV);
+        m_path = lane_mask(mode == M_PATH);
+        m_live = m_trav & lane_mask(tv.cur != RT_NONE);
         m_gated = SAH ? lane_mask(gated) : 0;
         m_nonfinite = ~(lane_mask(__builtin_isfinite(inv.x)) & lane_mask(__builtin_isfinite(inv.y)) & lane_mask(__builtin_isfinite(inv.z)));
     }
