@@ -224,6 +224,13 @@ __device__ __forceinline__ uint32_t shl1_add(uint32_t m, uint64_t lanes_of_b) {
     return r;
 }
 
+// p += bytes after a store through p + bytes: as C the compiler computes the sum once, before the store, into a second register
+// and copies it back where the branches join (add + move); the tied operand keeps it one instruction, in place, after the store
+template <uint32_t BYTES>
+__device__ __forceinline__ void bump_in_place(int& p) {
+    asm volatile("v_add_u32 %0, %1, %0" : "+v"(p) : "n"(BYTES) : "memory");
+}
+
 // Entry distance of a queued leaf, kept in 16 bits (LDS is what limits occupancy here): the
 // top half of the binary32 pattern.  Truncation rounds a positive distance down, so the re-check
 // when the leaf is taken up can only cull less than the full value would; a negative distance
@@ -280,8 +287,8 @@ struct TraceArgs {
     unsigned long long* counters; // 4
     float* stage;                 // launch waves x 2 slots x job_cap x 3: radiance of the samples of the jobs in flight
     unsigned int* work_counter;   // next job to hand out (zeroed before the launch)
-    int* stack_ovf;               // node stack entries beyond the LDS ones: entry e of launch lane g at [(e - stack_depth) * ovf_lanes + g]
-    uint32_t ovf_lanes;           // lanes of the launch (grid x 256)
+    int* stack_ovf;               // node stack entries beyond the LDS ones, a region per workgroup: entry e of thread t at [(e - stack_depth) * RT_BLOCK + t]
+    uint32_t ovf_block_bytes;     // bytes of a workgroup's region ((scene depth - stack_depth) x RT_BLOCK x 4)
     uint32_t n_jobs, n_tx, n_ty;  // jobs = n_ty x n_tx tiles of (1 << tile_lx) x (1 << tile_ly) pixels, each with all n_passes passes
     uint32_t tile_lx, tile_ly;
     uint32_t job_cap;             // samples a staging slot holds (>= pixels of a tile x n_passes)
@@ -313,8 +320,8 @@ __device__ __forceinline__ const MatDev* material_of(const DevScene& S, int idx)
 // it can take part in whichever kind of step the wave votes for.
 struct Trav {
     int cur;          // interior record to test next (its byte offset in nodes, >= 0), or RT_NONE
-    int sp;           // node stack entries
-    int lq;           // leaf queue entries
+    int sp;           // node stack: LDS address of the lane's top entry (trace_pixels)
+    int lq;           // leaf queue: entries, or (8-byte entries, RT_LQ64_OF) the LDS address of the top one
     int k;            // triangle slot in progress (its byte offset in tri_geo), or -1
     uint32_t mask;    // mesh roots still to visit (scenes of up to 32 meshes; larger ones start at the top-level tree)
     float best_t;
@@ -532,9 +539,26 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     // with two entries fewer in LDS), so those keep the 4 + 2-byte planes.  rt_hip.hip::trace_lds_bytes is the other half.
     constexpr bool LQ64 = RT_LQ64_OF(SAH, CULL, DEEP);
     int* s_leaf = (int*)(s_mem + n_root4 + RT_PC_F4) + threadIdx.x;
-    int2* s_leaf2 = (int2*)(s_mem + n_root4 + RT_PC_F4) + threadIdx.x;
     unsigned short* s_leaf_t = (unsigned short*)((int*)(s_mem + n_root4 + RT_PC_F4) + (size_t)n_ent * RT_BLOCK) + threadIdx.x;
-    int* s_stack = LQ64 ? (int*)(s_mem + n_root4 + RT_PC_F4) + (size_t)2 * LQ * RT_BLOCK + threadIdx.x : s_leaf + (size_t)LQ * RT_BLOCK;
+    // The node stack pointer and (LQ64) the leaf queue pointer are kept as the LDS ADDRESS of the lane's TOP entry (entry e of
+    // lane t lies e planes of RT_BLOCK entries above the lane's first one; empty = one plane below the first): a push is one
+    // add and a store, a pop a load and one subtract, both in place, and the emptiness tests compare against a uniform bound
+    // (a lane's first entry lies less than one plane above the base of the columns; signed compares, the empty address of a
+    // low column may be negative).  As an index each access costs a shift-add and a copy on top: five vector instructions
+    // per node step, one per triangle step.
+    typedef int i2v __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) int* lds_i;
+    typedef __attribute__((address_space(3))) i2v* lds_i2;
+    constexpr uint32_t ST_PLANE = 4u * RT_BLOCK, LQ_PLANE = 8u * RT_BLOCK;
+    const uint32_t col_base = (uint32_t)(uintptr_t)(lds_i)(int*)(s_mem + n_root4 + RT_PC_F4);        // uniform
+    const uint32_t st_base = col_base + (LQ64 ? 8u : 4u) * LQ * RT_BLOCK;
+    const uint32_t st_lim = st_base + (uint32_t)S.stack_depth * ST_PLANE;                              // DEEP: first entry beyond the LDS ones
+    // DEEP: the planes go on in the workgroup's region of stack_ovf, so an entry beyond st_lim is at this uniform base plus
+    // the same 32-bit address - no index arithmetic, the store / load takes the pointer register as its offset
+    const uintptr_t ovf_base = DEEP ? (uintptr_t)a.stack_ovf + (size_t)blockIdx.x * a.ovf_block_bytes - st_lim : 0;
+    const int st_empty = (int)(st_base + threadIdx.x * 4u) - (int)ST_PLANE, lq_empty = LQ64 ? (int)(col_base + threadIdx.x * 8u) - (int)LQ_PLANE : 0;
+    const auto lq_nonempty = [&](int lq) { return LQ64 ? lq >= (int)col_base : lq > 0; };
+    const auto lq_room_for_two = [&](int lq) { return LQ64 ? lq < (int)(col_base + (LQ - 2) * LQ_PLANE) : lq <= LQ - 2; };
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -573,7 +597,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     constexpr bool sah = SAH;  // the scene was built with RT_ACCEL_SAH (the tri_hit records carry the reference's leaf boxes)
     bool gated = false;        // SAH: the query in flight is a repeat with the reference-leaf-box gate on every hit
     Trav tv;
-    tv.cur = RT_NONE; tv.sp = 0; tv.lq = 0; tv.k = -1; tv.mask = 0;
+    tv.cur = RT_NONE; tv.sp = st_empty; tv.lq = lq_empty; tv.k = -1; tv.mask = 0;
     tv.best_t = 1e20f; tv.best_rank = RT_MISS_RANK;
     // Two per-lane flags of the query in flight, kept as lane masks of the wave (64-bit scalars that are only ever
     // assigned where the wave's control flow is uniform, so that they stay in scalar registers): node work may remain;
@@ -589,8 +613,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     while (true) {
         // =============== traversal phase: node steps / triangle steps chosen by vote ===============
         while (true) {
-            const uint64_t bT = lane_mask(tv.k >= 0) | lane_mask(tv.lq > 0);           // has leaf work
-            const uint64_t bN = m_live & lane_mask(tv.lq <= LQ - 2);                    // can take a node step
+            const uint64_t bT = lane_mask(tv.k >= 0) | lane_mask(lq_nonempty(tv.lq));  // has leaf work
+            const uint64_t bN = m_live & lane_mask(lq_room_for_two(tv.lq));             // can take a node step
             const bool can_node = in_mask(bN);
             m_fin = m_trav & ~bT & ~m_live;                                             // the query is finished
             const int cN = __popcll(bN), cT = __popcll(bT), cAny = __popcll(bN | bT);
@@ -655,36 +679,40 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         const int rn = second_near ? ref2 : ref1, rf = second_near ? ref1 : ref2;
                         const float tn = second_near ? t2a : t1a, tf = second_near ? t1a : t2a;
                         if (in_mask(m_hf & m_lf)) {
-                            if (LQ64) s_leaf2[tv.lq * RT_BLOCK] = make_int2(rf, __float_as_int(tf));
-                            else {
+                            if (LQ64) {
+                                *(lds_i2)(uintptr_t)((uint32_t)tv.lq + LQ_PLANE) = (i2v){rf, __float_as_int(tf)};
+                                bump_in_place<LQ_PLANE>(tv.lq);
+                            } else {
                                 s_leaf[tv.lq * RT_BLOCK] = rf;
                                 if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tf);
+                                tv.lq++;
                             }
-                            tv.lq++;
                         }
                         if (in_mask(m_hn & m_ln)) {
-                            if (LQ64) s_leaf2[tv.lq * RT_BLOCK] = make_int2(rn, __float_as_int(tn));
-                            else {
+                            if (LQ64) {
+                                *(lds_i2)(uintptr_t)((uint32_t)tv.lq + LQ_PLANE) = (i2v){rn, __float_as_int(tn)};
+                                bump_in_place<LQ_PLANE>(tv.lq);
+                            } else {
                                 s_leaf[tv.lq * RT_BLOCK] = rn;
                                 if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tn);
+                                tv.lq++;
                             }
-                            tv.lq++;
                         }
                         const uint64_t m_in = m_hn & ~m_ln, m_if = m_hf & ~m_lf;
                         if (in_mask(m_in & m_if)) {
-                            if (!DEEP || tv.sp < S.stack_depth) s_stack[tv.sp * RT_BLOCK] = rf;
-                            else a.stack_ovf[(size_t)(tv.sp - S.stack_depth) * a.ovf_lanes + (blockIdx.x * RT_BLOCK + threadIdx.x)] = rf;
-                            tv.sp++;
+                            if (!DEEP || tv.sp + (int)ST_PLANE < (int)st_lim) *(lds_i)(uintptr_t)((uint32_t)tv.sp + ST_PLANE) = rf;
+                            else *(int*)(ovf_base + (uint32_t)(tv.sp + (int)ST_PLANE)) = rf;
+                            bump_in_place<ST_PLANE>(tv.sp);
                         }
                         tv.cur = in_mask(m_in) ? rn : (in_mask(m_if) ? rf : RT_NONE);
                         // ---- no child to go on with: take up the next record NOW (a deferred far child, else the next mesh root),
                         // so that between steps "node work remains" is simply "a record is in hand" ----
                         if (tv.cur == RT_NONE) {
-                            if (tv.sp > 0) {
-                                tv.sp--;
-                                if (!DEEP || tv.sp < S.stack_depth) tv.cur = s_stack[tv.sp * RT_BLOCK];
+                            if (tv.sp >= (int)st_base) {
+                                if (!DEEP || tv.sp < (int)st_lim) tv.cur = *(lds_i)(uintptr_t)(uint32_t)tv.sp;
                                 else                                    // a rare deep entry (see stack_ovf)
-                                    tv.cur = a.stack_ovf[(size_t)(tv.sp - S.stack_depth) * a.ovf_lanes + (blockIdx.x * RT_BLOCK + threadIdx.x)];
+                                    tv.cur = *(const int*)(ovf_base + (uint32_t)tv.sp);
+                                tv.sp -= (int)ST_PLANE;
                             } else if (tv.mask) {                       // (a root in the table is never a leaf: rt_set_scene wraps those)
                                 const int b = __builtin_ctz(tv.mask);
                                 tv.mask &= tv.mask - 1;
@@ -705,9 +733,10 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     if (STATS) { sch.tri_steps++; sch.tri_lanes += __popcll(m_leaf); }
                     if (in_mask(m_leaf)) {
                         if (tv.k < 0) {                                 // take up the most recently found leaf
-                            tv.lq--;
+                            if (!LQ64) tv.lq--;
                             if (LQ64) {
-                                const int2 e = s_leaf2[tv.lq * RT_BLOCK];
+                                const i2v e = *(lds_i2)(uintptr_t)(uint32_t)tv.lq;
+                                tv.lq -= (int)LQ_PLANE;
                                 tv.k = RT_LEAF_OFFSET(e.x);
                                 if (__int_as_float(e.y) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS) tv.k = -1;
                             } else {
@@ -756,7 +785,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             tv.k = __float_as_int(g3.y);                    // the leaf's next slot, or -1
                         }
                     }
-                    m_leaf = lane_mask(tv.k >= 0) | lane_mask(tv.lq > 0);
+                    m_leaf = lane_mask(tv.k >= 0) | lane_mask(lq_nonempty(tv.lq));
                     cTn = __popcll(m_leaf);
                 } while (cTn > 0 && 8 * cTn >= a.burst8 * lim);
             }
@@ -1044,8 +1073,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         if (dst >= 0.0f && !(dst < 1e-6f) && dst < tv.best_t) { tv.best_t = dst; tv.best_rank = RT_SPHERE_RANK + i; }
                     }
                 }
-                tv.sp = 0;
-                tv.lq = 0;
+                tv.sp = st_empty;
+                tv.lq = lq_empty;
                 tv.k = -1;
                 const int tlas = __builtin_amdgcn_readfirstlane(PS.tlas_root);
                 if (tlas >= 0) {                                   // many meshes: start at the top-level tree

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_WAVES) void k_trace(TraceArgs a) {
 // runs on holds its own copy until the process ends; its DEVICE address is taken once per context
 // with hipGetSymbolAddress (rt_create) - in host code the name `scratch` is only a stand-in.
 //   [0, 256)                                 work counter
-//   [256, 256 + RT_STATIC_OVF_BYTES)         stack_ovf (int per deep entry and launch lane)
+//   [256, 256 + RT_STATIC_OVF_BYTES)         stack_ovf (int per deep entry and launch lane, a region per workgroup)
 //   [256 + RT_STATIC_OVF_BYTES, end)         stage (per wave: 2 slots x job_cap float3)
 #define RT_STATIC_OVF_BYTES ((size_t)16 << 20)
 #define RT_STATIC_STAGE_OFF ((size_t)256 + RT_STATIC_OVF_BYTES)
@@ -416,7 +416,7 @@ struct rt_ctx {
     int n_cus = 0;
     size_t lds_per_cu = 160 * 1024;
     int stack_lds[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // per k_trace variant: node stack entries in LDS for the scene in place
-    DevBuf<int> stack_ovf;                // deeper entries (rare): (stack_depth - cap) x launch lanes
+    DevBuf<int> stack_ovf;                // deeper entries (rare): per workgroup (stack_depth - cap) x RT_BLOCK
     size_t stack_ovf_n = 0;
     unsigned char* static_scratch = nullptr;   // device address of `scratch` on this context's GPU (hipGetSymbolAddress)
     bool launch_static = false;           // the launch in preparation belongs to rt_render_static: nothing may be allocated
@@ -730,7 +730,7 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
         }
         b.stack_ovf = c->stack_ovf.p;
     }
-    b.ovf_lanes = grid * RT_BLOCK;
+    b.ovf_block_bytes = (uint32_t)(deep * RT_BLOCK * sizeof(int));
     c->last_stack_lds = cap;
     c->last_lds_bytes = (int)lds;
     c->last_blocks_per_cu = c->blocks_per_cu[key];
