@@ -321,7 +321,7 @@ __device__ __forceinline__ const MatDev* material_of(const DevScene& S, int idx)
 struct Trav {
     int cur;          // interior record to test next (its byte offset in nodes, >= 0), or RT_NONE
     int sp;           // node stack: LDS address of the lane's top entry (trace_pixels)
-    int lq;           // leaf queue: entries, or (8-byte entries, RT_LQ64_OF) the LDS address of the top one
+    int lq;           // leaf queue: LDS address of the lane's top entry (trace_pixels)
     int k;            // triangle slot in progress (its byte offset in tri_geo), or -1
     uint32_t mask;    // mesh roots still to visit (scenes of up to 32 meshes; larger ones start at the top-level tree)
     float best_t;
@@ -538,27 +538,41 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     // LDS per workgroup, which a scene that needs the DEEP instantiation rather spends on stack entries (dragon scene: +1.8 %
     // with two entries fewer in LDS), so those keep the 4 + 2-byte planes.  rt_hip.hip::trace_lds_bytes is the other half.
     constexpr bool LQ64 = RT_LQ64_OF(SAH, CULL, DEEP);
-    int* s_leaf = (int*)(s_mem + n_root4 + RT_PC_F4) + threadIdx.x;
-    unsigned short* s_leaf_t = (unsigned short*)((int*)(s_mem + n_root4 + RT_PC_F4) + (size_t)n_ent * RT_BLOCK) + threadIdx.x;
-    // The node stack pointer and (LQ64) the leaf queue pointer are kept as the LDS ADDRESS of the lane's TOP entry (entry e of
+    // The node stack pointer and the leaf queue pointer are kept as the LDS ADDRESS of the lane's TOP entry (entry e of
     // lane t lies e planes of RT_BLOCK entries above the lane's first one; empty = one plane below the first): a push is one
     // add and a store, a pop a load and one subtract, both in place, and the emptiness tests compare against a uniform bound
     // (a lane's first entry lies less than one plane above the base of the columns; signed compares, the empty address of a
     // low column may be negative).  As an index each access costs a shift-add and a copy on top: five vector instructions
-    // per node step, one per triangle step.
+    // per node step, one per triangle step.  The leaf queue pointer runs over the 8-byte entries (LQ64), else over the 16-bit
+    // distance plane of the culling builds (the 4-byte entry of the same index is then at twice the address plus a uniform
+    // constant: one shift-add), else over the 4-byte entries themselves.
     typedef int i2v __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) int* lds_i;
     typedef __attribute__((address_space(3))) i2v* lds_i2;
-    constexpr uint32_t ST_PLANE = 4u * RT_BLOCK, LQ_PLANE = 8u * RT_BLOCK;
+    typedef __attribute__((address_space(3))) unsigned short* lds_h;
+    constexpr bool LQ16 = !LQ64 && CULL != 0;
+    constexpr uint32_t ST_PLANE = 4u * RT_BLOCK, LQ_PLANE = (LQ64 ? 8u : LQ16 ? 2u : 4u) * RT_BLOCK;
     const uint32_t col_base = (uint32_t)(uintptr_t)(lds_i)(int*)(s_mem + n_root4 + RT_PC_F4);        // uniform
+    const uint32_t lq_base = LQ16 ? col_base + (uint32_t)n_ent * ST_PLANE : col_base;                  // plane the queue pointer runs over
+    const uint32_t lq_int_k = col_base - 2u * lq_base;                                                // LQ16: 4-byte entry at 2 * pointer + this
     const uint32_t st_base = col_base + (LQ64 ? 8u : 4u) * LQ * RT_BLOCK;
     const uint32_t st_lim = st_base + (uint32_t)S.stack_depth * ST_PLANE;                              // DEEP: first entry beyond the LDS ones
     // DEEP: the planes go on in the workgroup's region of stack_ovf, so an entry beyond st_lim is at this uniform base plus
     // the same 32-bit address - no index arithmetic, the store / load takes the pointer register as its offset
     const uintptr_t ovf_base = DEEP ? (uintptr_t)a.stack_ovf + (size_t)blockIdx.x * a.ovf_block_bytes - st_lim : 0;
-    const int st_empty = (int)(st_base + threadIdx.x * 4u) - (int)ST_PLANE, lq_empty = LQ64 ? (int)(col_base + threadIdx.x * 8u) - (int)LQ_PLANE : 0;
-    const auto lq_nonempty = [&](int lq) { return LQ64 ? lq >= (int)col_base : lq > 0; };
-    const auto lq_room_for_two = [&](int lq) { return LQ64 ? lq < (int)(col_base + (LQ - 2) * LQ_PLANE) : lq <= LQ - 2; };
+    const int st_empty = (int)(st_base + threadIdx.x * 4u) - (int)ST_PLANE;
+    const int lq_empty = (int)(lq_base + threadIdx.x * (LQ_PLANE / RT_BLOCK)) - (int)LQ_PLANE;
+    const auto lq_nonempty = [&](int lq) { return lq >= (int)lq_base; };
+    const auto lq_room_for_two = [&](int lq) { return lq < (int)(lq_base + (LQ - 2) * LQ_PLANE); };
+    const auto lq_push = [&](int& lq, int ref, float dist) {
+        const uint32_t at = (uint32_t)lq + LQ_PLANE;
+        if (LQ64) *(lds_i2)(uintptr_t)at = (i2v){ref, __float_as_int(dist)};
+        else if (LQ16) {
+            *(lds_i)(uintptr_t)(2u * at + lq_int_k) = ref;
+            *(lds_h)(uintptr_t)at = pack_dist(dist);
+        } else *(lds_i)(uintptr_t)at = ref;
+        bump_in_place<LQ_PLANE>(lq);
+    };
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -679,24 +693,10 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         const int rn = second_near ? ref2 : ref1, rf = second_near ? ref1 : ref2;
                         const float tn = second_near ? t2a : t1a, tf = second_near ? t1a : t2a;
                         if (in_mask(m_hf & m_lf)) {
-                            if (LQ64) {
-                                *(lds_i2)(uintptr_t)((uint32_t)tv.lq + LQ_PLANE) = (i2v){rf, __float_as_int(tf)};
-                                bump_in_place<LQ_PLANE>(tv.lq);
-                            } else {
-                                s_leaf[tv.lq * RT_BLOCK] = rf;
-                                if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tf);
-                                tv.lq++;
-                            }
+                            lq_push(tv.lq, rf, tf);
                         }
                         if (in_mask(m_hn & m_ln)) {
-                            if (LQ64) {
-                                *(lds_i2)(uintptr_t)((uint32_t)tv.lq + LQ_PLANE) = (i2v){rn, __float_as_int(tn)};
-                                bump_in_place<LQ_PLANE>(tv.lq);
-                            } else {
-                                s_leaf[tv.lq * RT_BLOCK] = rn;
-                                if (CULL) s_leaf_t[tv.lq * RT_BLOCK] = pack_dist(tn);
-                                tv.lq++;
-                            }
+                            lq_push(tv.lq, rn, tn);
                         }
                         const uint64_t m_in = m_hn & ~m_ln, m_if = m_hf & ~m_lf;
                         if (in_mask(m_in & m_if)) {
@@ -733,18 +733,16 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     if (STATS) { sch.tri_steps++; sch.tri_lanes += __popcll(m_leaf); }
                     if (in_mask(m_leaf)) {
                         if (tv.k < 0) {                                 // take up the most recently found leaf
-                            if (!LQ64) tv.lq--;
+                            const float beyond = fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS;
                             if (LQ64) {
                                 const i2v e = *(lds_i2)(uintptr_t)(uint32_t)tv.lq;
-                                tv.lq -= (int)LQ_PLANE;
                                 tv.k = RT_LEAF_OFFSET(e.x);
-                                if (__int_as_float(e.y) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS) tv.k = -1;
-                            } else {
-                                const int ref = s_leaf[tv.lq * RT_BLOCK];
-                                tv.k = RT_LEAF_OFFSET(ref);
-                                if (CULL && unpack_dist(s_leaf_t[tv.lq * RT_BLOCK]) > fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS)
-                                    tv.k = -1;
-                            }
+                                if (__int_as_float(e.y) > beyond) tv.k = -1;
+                            } else if (LQ16) {
+                                tv.k = RT_LEAF_OFFSET(*(lds_i)(uintptr_t)(2u * (uint32_t)tv.lq + lq_int_k));
+                                if (unpack_dist(*(lds_h)(uintptr_t)(uint32_t)tv.lq) > beyond) tv.k = -1;
+                            } else tv.k = RT_LEAF_OFFSET(*(lds_i)(uintptr_t)(uint32_t)tv.lq);
+                            tv.lq -= (int)LQ_PLANE;
                         }
                         if (tv.k >= 0) {                                // one triangle of the leaf (:593-630)
                             // tv.k is the slot's 32-bit byte offset from a uniform base: no shift, no 64-bit address arithmetic
