@@ -957,7 +957,10 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             need = fresh && !have;
         }
         if (!FIRST_HIT) {                                          // samples finished in this block, per job slot (wave-uniform)
-            const uint64_t c0 = lane_mask(completed && elem < P.job_cap), c1 = lane_mask(completed && elem >= P.job_cap);
+            // (one ballot of the flag, split by a compare: the ballot of a boolean that was merged across branches costs a select
+            // and a compare, that of a compare only the compare)
+            const uint64_t c_all = lane_mask(completed), c_lo = lane_mask(elem < P.job_cap);
+            const uint64_t c0 = c_all & c_lo, c1 = c_all & ~c_lo;
             if (lane == 0) {
                 if (c0) wj->done[0] = (uint16_t)(wj->done[0] + __popcll(c0));
                 if (c1) wj->done[1] = (uint16_t)(wj->done[1] + __popcll(c1));
