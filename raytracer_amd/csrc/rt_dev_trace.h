@@ -623,11 +623,12 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     // vote computes anyway); its `mode` register is brought up to date once, when the loop is left - a compare and a select
     // fewer in every trip of the vote.
     uint64_t m_trav = 0, m_path = ~0ull, m_fin = 0;
+    uint64_t m_k = 0;          // lanes with a triangle in progress (tv.k >= 0): changes in triangle steps and at a query's start only
 
     while (true) {
         // =============== traversal phase: node steps / triangle steps chosen by vote ===============
         while (true) {
-            const uint64_t bT = lane_mask(tv.k >= 0) | lane_mask(lq_nonempty(tv.lq));  // has leaf work
+            const uint64_t bT = m_k | lane_mask(lq_nonempty(tv.lq));                    // has leaf work
             const uint64_t bN = m_live & lane_mask(lq_room_for_two(tv.lq));             // can take a node step
             const bool can_node = in_mask(bN);
             m_fin = m_trav & ~bT & ~m_live;                                             // the query is finished
@@ -783,7 +784,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             tv.k = __float_as_int(g3.y);                    // the leaf's next slot, or -1
                         }
                     }
-                    m_leaf = lane_mask(tv.k >= 0) | lane_mask(lq_nonempty(tv.lq));
+                    m_k = lane_mask(tv.k >= 0);
+                    m_leaf = m_k | lane_mask(lq_nonempty(tv.lq));
                     cTn = __popcll(m_leaf);
                 } while (cTn > 0 && 8 * cTn >= a.burst8 * lim);
             }
@@ -1101,6 +1103,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
         // same values: node work remains <=> a record in hand, a deferred one or a root left) for those still in flight.
         // A lane without a query keeps the 1/d of its last one; its bit in m_nonfinite is never looked at.
         m_trav = lane_mask(mode == M_TRAV);
+        m_k = lane_mask(tv.k >= 0);
         m_path = lane_mask(mode == M_PATH);
         m_live = m_trav & lane_mask(tv.cur != RT_NONE);
         m_gated = SAH ? lane_mask(gated) : 0;
