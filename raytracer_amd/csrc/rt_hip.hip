@@ -650,8 +650,9 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.burst8 = c->burst8 >= 0 ? c->burst8 : (c->scene_is_sah ? 3 : 4);
     a.recheck_all = c->recheck_all;
     // best measured (tools/sweep_sched.sh): a scene that lives in the L2 gains from shading fuller path blocks,
-    // one that does not (991 k triangles) from refilling earlier (28 since round 3: tools/sweep_inproc.py); a scene with a top-level tree (long traversals) shades fuller still
-    a.refill_below = c->refill_below > 0 ? c->refill_below : (!c->cull ? 32 : !c->scene_is_sah ? 28 : c->n_slots > 100000 ? 28 : c->tlas_root >= 0 ? 16 : 20);
+    // one that does not (991 k triangles) from refilling earlier (28 since round 3: tools/sweep_inproc.py); a scene with a top-level tree (long traversals) shades fuller still;
+    // the root-table scenes went from 20 to 22 when round 3 made the path block cheaper (profiles/r03_sched_sweep.txt)
+    a.refill_below = c->refill_below > 0 ? c->refill_below : (!c->cull ? 32 : !c->scene_is_sah ? 28 : c->n_slots > 100000 ? 28 : c->tlas_root >= 0 ? 16 : 22);
 }
 
 // dynamic LDS of a k_trace launch: root table + kernel-argument copy + per-lane node stack and leaf

@@ -84,7 +84,7 @@ def test_million_triangles(oracle_lib, hip_lib):
 @pytest.mark.parametrize("mode", [1, 2])
 def test_million_triangles_sah_culled_deep_vs_oracle(oracle_lib, hip_lib, mode):
     """The mode `bench.py --workload subdiv4k` times: 991 316 triangles on the SAH structure with distance culling, node
-    stack deeper than its LDS part (DEEP instantiation, the scheduler's refill_below 24 branch for scenes that do not fit
+    stack deeper than its LDS part (DEEP instantiation, the scheduler's refill_below 28 branch for scenes that do not fit
     the L2) - against the ORACLE (raytracer.fs.glsl:518-641 restated), not only against the exact mode.  mode 2 = the
     distance band alone (rt_set_cull(ctx, RT_CULL_BAND))."""
     sc = _scene(5, hip_lib, frame=7)
