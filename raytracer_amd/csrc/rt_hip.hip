@@ -104,14 +104,38 @@ __global__ __launch_bounds__(256) void k_tri_flags(const int* slot_mesh, const M
 // visited-node table: c1/c2 = child visit indices (-1 none); leaves: [start, start+count) slots
 struct VNode { int c1, c2, start, count; };
 
-__global__ __launch_bounds__(256) void k_refit_level(const VNode* vn, const int* level_nodes, int n, const float4* geo, float4* nbox) {
+// SAH structure only: how far beyond a vertex rayTriangle can accept a point.  An edge function N.((B-A)x(P-A)) carries a
+// rounding error of <= ~10 x 2^-24 |N||B-A||P-A|, i.e. it accepts points up to ~10 x 2^-24 D outside its edge (D = the
+// longest edge) - at a vertex of angle theta that is up to 10 x 2^-24 D / sin(theta) beyond the tip, along the adjacent
+// edge, which for a sliver exceeds any fixed slack.  So every box carries, on top of its slack, the largest
+// 2^-19 D / sin(theta_min) of the triangles below it (sin(theta_min) = |N| / product of the two longest edges; a few 10^-6 D
+// for ordinary triangles): the refit hands it up in the free .w lane of the box minima, k_pack_nodes adds it to the slack.
+// It must widen the TEST, not the stored box: a stored box that is larger by even 10^-6 is no longer left at t < 5e-7 by the
+// bounce ray that starts on it, and culling rule (b) stops discarding it (measured: 40.7 -> 51.4 ms).  A triangle with
+// |N| = 0 is never hit (|N.d| < 1e-6); the pad is capped at D.  0 for the reference's own structure: its tests are the
+// reference's.
+__device__ __forceinline__ float sliver_tip_pad(float4 g0, float4 g1, float4 g2) {
+    const float ab = (g1.x - g0.x) * (g1.x - g0.x) + (g1.y - g0.y) * (g1.y - g0.y) + (g1.z - g0.z) * (g1.z - g0.z);
+    const float bc = (g2.x - g1.x) * (g2.x - g1.x) + (g2.y - g1.y) * (g2.y - g1.y) + (g2.z - g1.z) * (g2.z - g1.z);
+    const float ca = (g0.x - g2.x) * (g0.x - g2.x) + (g0.y - g2.y) * (g0.y - g2.y) + (g0.z - g2.z) * (g0.z - g2.z);
+    const float l1 = fmaxf(ab, fmaxf(bc, ca)), l3 = fminf(ab, fminf(bc, ca)), l2 = ab + bc + ca - l1 - l3;   // squared edge lengths, sorted
+    const float n2 = g0.w * g0.w + g1.w * g1.w + g2.w * g2.w;           // |N|^2, N = (B-A)x(C-A) (k_pose)
+    const float d = sqrtf(l1);
+    if (!(n2 > 0.0f)) return 0.0f;
+    const float pad = 0x1p-19f * d * sqrtf(l1 * fmaxf(l2, 0.0f) / n2);
+    return pad < d ? pad : d;                                            // (a NaN from overflow compares false: capped)
+}
+
+__global__ __launch_bounds__(256) void k_refit_level(const VNode* vn, const int* level_nodes, int n, const float4* geo, float4* nbox, int sah) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int v = level_nodes[i];
     VNode nd = vn[v];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float pad = 0.0f;
     if (nd.c1 < 0 && nd.c2 < 0) {
         for (int k = nd.start; k < nd.start + nd.count; k++) {
+            if (sah) pad = fmaxf(pad, sliver_tip_pad(geo[4 * (size_t)k], geo[4 * (size_t)k + 1], geo[4 * (size_t)k + 2]));
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 float4 p = geo[4 * (size_t)k + c];
@@ -126,12 +150,13 @@ __global__ __launch_bounds__(256) void k_refit_level(const VNode* vn, const int*
         for (int s = 0; s < 2; s++) {
             if (ch[s] < 0) continue;
             float4 a = nbox[2 * (size_t)ch[s]], b = nbox[2 * (size_t)ch[s] + 1];
+            pad = fmaxf(pad, a.w);
             lo[0] = a.x < lo[0] ? a.x : lo[0]; hi[0] = b.x > hi[0] ? b.x : hi[0];
             lo[1] = a.y < lo[1] ? a.y : lo[1]; hi[1] = b.y > hi[1] ? b.y : hi[1];
             lo[2] = a.z < lo[2] ? a.z : lo[2]; hi[2] = b.z > hi[2] ? b.z : hi[2];
         }
     }
-    nbox[2 * (size_t)v] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    nbox[2 * (size_t)v] = make_float4(lo[0], lo[1], lo[2], pad);
     nbox[2 * (size_t)v + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
 }
 
@@ -148,7 +173,7 @@ __host__ __device__ __forceinline__ int dev_ref(int ref) {
 __device__ __forceinline__ float box_slack(float4 lo, float4 hi, int sah) {
     if (!sah) return 0.0f;
     const float m = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
-    return 2.0f * (m * 0x1p-16f + 0x1p-20f);
+    return 2.0f * (m * 0x1p-16f + 0x1p-20f + lo.w);       // lo.w: the subtree's sliver-tip pad (k_refit_level)
 }
 
 // one thread per leaf of the REFERENCE's tree: box of its (posed) triangles, written to the hit record of every member slot
@@ -191,8 +216,9 @@ __global__ __launch_bounds__(256) void k_pack_nodes(const PackInfo* pi, int n_re
         const bool a1 = p.c1 >= 0 && p.ref1 != RT_IDX_NONE, a2 = p.c2 >= 0 && p.ref2 != RT_IDX_NONE;
         float4 lo1 = a1 ? nbox[2 * (size_t)p.c1] : zn, hi1 = a1 ? nbox[2 * (size_t)p.c1 + 1] : zn;
         float4 lo2 = a2 ? nbox[2 * (size_t)p.c2] : zn, hi2 = a2 ? nbox[2 * (size_t)p.c2 + 1] : zn;
-        lo2.w = a1 ? box_slack(lo1, hi1, pad) : qn;
-        hi2.w = a2 ? box_slack(lo2, hi2, pad) : qn;
+        const float s1 = a1 ? box_slack(lo1, hi1, pad) : qn, s2 = a2 ? box_slack(lo2, hi2, pad) : qn;   // (both read their box's .w)
+        lo2.w = s1;
+        hi2.w = s2;
         lo1.w = __int_as_float(dev_ref(p.ref1));
         hi1.w = __int_as_float(dev_ref(p.ref2));
         float4* o = nodes + 4 * (size_t)i;
@@ -598,7 +624,7 @@ int run_prep(rt_ctx* c) {
         int n = c->level_off[l + 1] - c->level_off[l];
         if (n <= 0) continue;
         hipLaunchKernelGGL(k_refit_level, dim3(blocks_for(n)), dim3(256), 0, c->stream, c->vnodes.p,
-                           c->level_nodes.p + c->level_off[l], n, c->geo.p, c->nbox.p);
+                           c->level_nodes.p + c->level_off[l], n, c->geo.p, c->nbox.p, c->scene_is_sah ? 1 : 0);
     }
     size_t m = (size_t)std::max(c->n_rec, c->n_roots);
     if (m)
