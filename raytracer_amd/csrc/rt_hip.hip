@@ -112,8 +112,7 @@ struct VNode { int c1, c2, start, count; };
 // for ordinary triangles): the refit hands it up in the free .w lane of the box minima, k_pack_nodes adds it to the slack.
 // It must widen the TEST, not the stored box: a stored box that is larger by even 10^-6 is no longer left at t < 5e-7 by the
 // bounce ray that starts on it, and culling rule (b) stops discarding it (measured: 40.7 -> 51.4 ms).  A triangle with
-// |N| = 0 is never hit (|N.d| < 1e-6); the pad is capped at D.  0 for the reference's own structure: its tests are the
-// reference's.
+// |N| = 0 is never hit (|N.d| < 1e-6).  0 for the reference's own structure: its tests are the reference's.
 __device__ __forceinline__ float sliver_tip_pad(float4 g0, float4 g1, float4 g2) {
     const float ab = (g1.x - g0.x) * (g1.x - g0.x) + (g1.y - g0.y) * (g1.y - g0.y) + (g1.z - g0.z) * (g1.z - g0.z);
     const float bc = (g2.x - g1.x) * (g2.x - g1.x) + (g2.y - g1.y) * (g2.y - g1.y) + (g2.z - g1.z) * (g2.z - g1.z);
@@ -123,7 +122,7 @@ __device__ __forceinline__ float sliver_tip_pad(float4 g0, float4 g1, float4 g2)
     const float d = sqrtf(l1);
     if (!(n2 > 0.0f)) return 0.0f;
     const float pad = 0x1p-19f * d * sqrtf(l1 * fmaxf(l2, 0.0f) / n2);
-    return pad < d ? pad : d;                                            // (a NaN from overflow compares false: capped)
+    return pad == pad ? pad : INFINITY;                                  // (not capped: an infinite slack only means "always enter")
 }
 
 __global__ __launch_bounds__(256) void k_refit_level(const VNode* vn, const int* level_nodes, int n, const float4* geo, float4* nbox, int sah) {
@@ -471,6 +470,7 @@ struct rt_ctx {
     int n_tris = 0, n_slots = 0, n_meshes = 0, n_nodes = 0, n_visit = 0, n_rec = 0, n_spheres = 0;
     int n_roots = 0;                      // entries of the root table: one per mesh, or per group of meshes (SAH structure, sah_group_below)
     int treelet = 8;                      // RT_TREELET: interior records laid out in breadth-first blocks of this many (0 = depth-first order)
+    bool sah_tip_pad = true;              // RT_SAH_TIP_PAD=0: the SAH boxes' slack without the sliver-tip pad (tests: what the pad is for)
     int sah_group_below = 0;              // RT_SAH_GROUP_BELOW: meshes with fewer triangles share one SAH tree (0 = one tree per mesh)
     int stack_depth = 1;
     int tlas_above = 32;                  // scenes with more meshes than this get the top-level tree (the LDS root mask holds 32)
@@ -624,7 +624,7 @@ int run_prep(rt_ctx* c) {
         int n = c->level_off[l + 1] - c->level_off[l];
         if (n <= 0) continue;
         hipLaunchKernelGGL(k_refit_level, dim3(blocks_for(n)), dim3(256), 0, c->stream, c->vnodes.p,
-                           c->level_nodes.p + c->level_off[l], n, c->geo.p, c->nbox.p, c->scene_is_sah ? 1 : 0);
+                           c->level_nodes.p + c->level_off[l], n, c->geo.p, c->nbox.p, c->scene_is_sah && c->sah_tip_pad ? 1 : 0);
     }
     size_t m = (size_t)std::max(c->n_rec, c->n_roots);
     if (m)
@@ -893,6 +893,7 @@ int rt_create(int device, rt_ctx** out) {
     c->stream = c->own_stream;
     if (const char* e = getenv("RT_SAH_LEAF")) c->sah_leaf = std::max(1, std::min(64, atoi(e)));
     if (const char* e = getenv("RT_SAH_GROUP_BELOW")) c->sah_group_below = std::max(0, atoi(e));
+    if (const char* e = getenv("RT_SAH_TIP_PAD")) c->sah_tip_pad = atoi(e) != 0;
     if (const char* e = getenv("RT_TREELET")) c->treelet = std::max(0, atoi(e));
     if (const char* e = getenv("RT_TLAS_STATIC")) c->tlas_static = atoi(e) != 0;
     if (const char* e = getenv("RT_TLAS_ABOVE")) c->tlas_above = std::max(1, std::min(32, atoi(e)));
