@@ -184,10 +184,11 @@ __device__ __forceinline__ bool culled(float tmin, float tmax, float best_t) {
 }
 
 // SAH structure only.  Its boxes are not the reference's, so their slab tests are made
-// conservative: a box counts as hit when  tmin <= tmax + (e2 + 2^-16 max|o|) * max|1/d|, where
-// e2 = 2 * (2^-16 max|box coordinate| + 2^-20) is stored with the box.  That is the slab test of
-// the box widened by at least e2/2 + 2^-17 max|o| on every side (each axis widens its interval
-// by e|1/d_a| <= e max|1/d|), ~100 x the rounding of the slab and edge arithmetic, so a ray whose
+// conservative: a box counts as hit when  tmin <= tmax + (e2 + 2^-18 max|o|) * max|1/d|, where
+// e2 = 2 * (2^-18 max|box coordinate| + 2^-22 + pad) is stored with the box (pad: the triangles' edge and sliver-tip
+// overshoot, rt_hip.hip::sliver_tip_pad).  That is the slab test of the box widened by at least e2/2 + 2^-19 max|o| on every
+// side (each axis widens its interval by e|1/d_a| <= e max|1/d|): 16 x / 10 x the rounding of the slab arithmetic and of the
+// hit point (<= 4 x 2^-24 of the coordinates + 3 x 2^-24 of the origin; derivation in DESIGN.md 5), so a ray whose
 // triangle test can pass always reaches the triangle.  The unwidened [tmin, tmax] still drives
 // the culling rules and the near-first order.  Which triangles COUNT is decided by the
 // reference's own leaf box (in the hit record, see the path block).
@@ -195,7 +196,7 @@ __device__ __forceinline__ float sah_slack(v3 o, v3 inv) {
     return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(inv.x), __builtin_fabsf(inv.y)), __builtin_fabsf(inv.z));
 }
 __device__ __forceinline__ float sah_org(v3 o) {
-    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z)) * 0x1p-16f;
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z)) * 0x1p-18f;
 }
 __device__ __forceinline__ bool sah_widened_hit(float tmin, float tmax, float e2, float mo, float mi) {
     return tmin <= fma_(e2 + mo, mi, tmax);

@@ -104,15 +104,15 @@ __global__ __launch_bounds__(256) void k_tri_flags(const int* slot_mesh, const M
 // visited-node table: c1/c2 = child visit indices (-1 none); leaves: [start, start+count) slots
 struct VNode { int c1, c2, start, count; };
 
-// SAH structure only: how far beyond a vertex rayTriangle can accept a point.  An edge function N.((B-A)x(P-A)) carries a
-// rounding error of <= ~10 x 2^-24 |N||B-A||P-A|, i.e. it accepts points up to ~10 x 2^-24 D outside its edge (D = the
-// longest edge) - at a vertex of angle theta that is up to 10 x 2^-24 D / sin(theta) beyond the tip, along the adjacent
+// SAH structure only: how far outside a triangle rayTriangle can accept a point.  An edge function N.((B-A)x(P-A)) carries a
+// rounding error of <= 14 x 2^-24 |N||B-A||P-A|, i.e. it accepts points up to 14 x 2^-24 D outside its edge
+// (D = the longest edge) - and at a vertex of angle theta up to 14 x 2^-24 D / sin(theta) beyond the tip, along the adjacent
 // edge, which for a sliver exceeds any fixed slack.  So every box carries, on top of its slack, the largest
-// 2^-19 D / sin(theta_min) of the triangles below it (sin(theta_min) = |N| / product of the two longest edges; a few 10^-6 D
-// for ordinary triangles): the refit hands it up in the free .w lane of the box minima, k_pack_nodes adds it to the slack.
-// It must widen the TEST, not the stored box: a stored box that is larger by even 10^-6 is no longer left at t < 5e-7 by the
-// bounce ray that starts on it, and culling rule (b) stops discarding it (measured: 40.7 -> 51.4 ms).  A triangle with
-// |N| = 0 is never hit (|N.d| < 1e-6).  0 for the reference's own structure: its tests are the reference's.
+// 2^-18 D + 2^-19 D / sin(theta_min) of the triangles below it (sin(theta_min) = |N| / product of the two longest edges; a few
+// 10^-6 D for ordinary triangles): the refit hands it up in the free .w lane of the box minima, k_pack_nodes adds it to the
+// slack.  It must widen the TEST, not the stored box: a stored box that is larger by even 10^-6 is no longer left at
+// t < 5e-7 by the bounce ray that starts on it, and culling rule (b) stops discarding it (measured: 40.7 -> 51.4 ms).  A
+// triangle with |N| = 0 is never hit (|N.d| < 1e-6).  0 for the reference's own structure: its tests are the reference's.
 __device__ __forceinline__ float sliver_tip_pad(float4 g0, float4 g1, float4 g2) {
     const float ab = (g1.x - g0.x) * (g1.x - g0.x) + (g1.y - g0.y) * (g1.y - g0.y) + (g1.z - g0.z) * (g1.z - g0.z);
     const float bc = (g2.x - g1.x) * (g2.x - g1.x) + (g2.y - g1.y) * (g2.y - g1.y) + (g2.z - g1.z) * (g2.z - g1.z);
@@ -121,7 +121,7 @@ __device__ __forceinline__ float sliver_tip_pad(float4 g0, float4 g1, float4 g2)
     const float n2 = g0.w * g0.w + g1.w * g1.w + g2.w * g2.w;           // |N|^2, N = (B-A)x(C-A) (k_pose)
     const float d = sqrtf(l1);
     if (!(n2 > 0.0f)) return 0.0f;
-    const float pad = 0x1p-19f * d * sqrtf(l1 * fmaxf(l2, 0.0f) / n2);
+    const float pad = 0x1p-19f * d * sqrtf(l1 * fmaxf(l2, 0.0f) / n2) + 0x1p-18f * d;    // beyond a tip + outside an edge (<= 14 x 2^-24 D)
     return pad == pad ? pad : INFINITY;                                  // (not capped: an infinite slack only means "always enter")
 }
 
@@ -167,12 +167,12 @@ __host__ __device__ __forceinline__ int dev_ref(int ref) {
 }
 
 // SAH structure: each box carries the slack of its widened slab test (rt_dev_trace.h,
-// sah_widened_hit): e2 = 2 * (2^-16 of its largest coordinate + 2^-20).  0 for the reference's
+// sah_widened_hit): e2 = 2 * (2^-18 of its largest coordinate + 2^-22 + the triangles' pad).  0 for the reference's
 // structure, whose tests are the reference's own.
 __device__ __forceinline__ float box_slack(float4 lo, float4 hi, int sah) {
     if (!sah) return 0.0f;
     const float m = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
-    return 2.0f * (m * 0x1p-16f + 0x1p-20f + lo.w);       // lo.w: the subtree's sliver-tip pad (k_refit_level)
+    return 2.0f * (m * 0x1p-18f + 0x1p-22f + lo.w);       // lo.w: the subtree's triangle pad (k_refit_level)
 }
 
 // one thread per leaf of the REFERENCE's tree: box of its (posed) triangles, written to the hit record of every member slot

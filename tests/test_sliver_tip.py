@@ -45,7 +45,7 @@ def test_points_beyond_a_sliver_tip_are_accepted_and_the_pad_covers_them():
         if h is not None:
             worst = max(worst, float(max(np.max(lo - h["hitPoint"]), np.max(h["hitPoint"] - hi))))
     m = float(np.max(np.abs(np.concatenate([lo, hi]))))
-    widened_without_pad = 2.0 ** -16 * m + 2.0 ** -20 + 2.0 ** -17 * 1.0        # e2 / 2 + 2^-17 max|o| (rt_dev_trace.h)
+    widened_without_pad = 2.0 ** -16 * m + 2.0 ** -20 + 2.0 ** -17 * 1.0        # rounds 1-2: e2 / 2 + 2^-17 max|o| (now a quarter of it)
     pad = _pad_as_the_kernel_computes_it(tri)
     assert worst > widened_without_pad, (worst, widened_without_pad)            # the gap is real ...
     assert worst < 0.05 * pad, (worst, pad)                                    # ... and the pad covers it 20 times over
