@@ -312,8 +312,9 @@ def main() -> None:
 
     if rank == 0:
         deep = info["stack_entries_lds"] < info["stack_entries"]
-        kernel = "k_trace<STATS=false,CULL=%s,FIRST_HIT=false,SAH=%s,DEEP=%s>" % (
-            "0" if args.strict else "1", "false" if args.reference_structure else "true", "true" if deep else "false")
+        kernel = "k_trace<STATS=false,CULL=%s,FIRST_HIT=false,SAH=%s,DEEP=%s,ROCT=%s>" % (
+            "0" if args.strict else "1", "false" if args.reference_structure else "true", "true" if deep else "false",
+            "true" if info.get("root_table_variants") == 8 else "false")
         hbm_frac = (traffic / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if (traffic and kern_ms > 0) else None
         out = {
             "metric": "Mrays/sec, Suzanne 1080p (rays = closest-hit queries, counted in-kernel)" if args.workload == "suzanne1080"

@@ -83,7 +83,9 @@ typedef struct rt_info_t {
     int32_t workgroups_per_cu;  /* resident workgroups per CU of that launch                               */
     int32_t top_level_rebuilds; /* times the top-level tree was rebuilt from posed boxes                   */
     int32_t n_roots;            /* entries of the root table: one per mesh, fewer when small meshes share a tree */
-    int32_t reserved[6];
+    int32_t root_table_variants;/* copies of the root table that launch's kernel kept in LDS: 8 = one per direction
+                                   octant (small SAH scenes), 1 = the plain table, 0 = no launch yet / oracle */
+    int32_t reserved[5];
 } rt_info_t;
 
 /* replaces: ProgramABC.__init__/initialise creating the GL context (application.py:499-575) */

@@ -174,6 +174,27 @@ __device__ __forceinline__ bool box_test_finite(v3 o, v3 inv, float4 lo, float4 
     return tmin <= tmax;
 }
 
+// Octant form of the same test (round 3; the ROCT instantiations' root loop).  For a ray with finite 1/d the per-axis entry /
+// exit values of the min/max form follow from the SIGN of 1/d alone: a box has lo <= hi, float subtraction and multiplication
+// are monotonic, so with 1/d > 0  (lo - o) * (1/d) <= (hi - o) * (1/d)  and min(a, b) IS a, max(a, b) IS b (where the two
+// coincide the sign of a zero may differ: every use of the interval is a comparison); with 1/d < 0 the other way round.  A table
+// that holds each box once per direction octant, every axis already in (near, far) order, is therefore tested with six
+// subtract / multiply pairs, one max3 and one min3: six min / max fewer per box, at 4.7 issue cycles each where the f32
+// arithmetic costs 2.4 (tools/ubench/valu_rate.hip).  An all-NaN box (a mesh without triangles) is NaN in either order.
+__device__ __forceinline__ bool box_test_oct(v3 o, v3 inv, float4 near, float4 far, float& tmin_out, float& tmax_out) {
+    const float ax = (near.x - o.x) * inv.x, bx = (far.x - o.x) * inv.x;
+    const float ay = (near.y - o.y) * inv.y, by = (far.y - o.y) * inv.y;
+    const float az = (near.z - o.z) * inv.z, bz = (far.z - o.z) * inv.z;
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
+    const float tmax = __builtin_fminf(__builtin_fminf(bx, by), bz);
+    tmin_out = tmin;
+    tmax_out = tmax;
+    return tmin <= tmax;
+}
+// the octant bit of an axis: 1/d negative (v_cmp_class: negative normal | negative denormal; the table is only read by rays
+// whose 1/d are all finite, the others take the compare ladder on the plain (lo, hi) table)
+__device__ __forceinline__ bool oct_axis_bit(float inv_a) { return __builtin_amdgcn_classf(inv_a, (1 << 3) | (1 << 4)); }
+
 // true when the culling rules allow skipping a box with interval [tmin,tmax]; NaN never culls.
 // CULL: RT_CULL_OFF (0) no rule, RT_CULL_ON (1) both rules, RT_CULL_BAND (2) the distance band alone (rule (a): the
 // only way it can drop a hit is a triangle distance that is off by more than the band)
@@ -333,7 +354,7 @@ struct Trav {
 // root box the ray's line touches.  A leaf root is tested as the reference does (:586); for an
 // interior root the test is an exact shortcut: child boxes nest inside it and float
 // subtract/multiply are monotonic, so no child test could pass when the root test fails.
-template <bool STATS, int CULL, bool FINITE>
+template <bool STATS, int CULL, bool FINITE, bool ROCT>
 __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn, v3 org, v3 inv, float best_t, bool sah, Counters& cnt, int& nearest) {
     uint32_t mask = 0;
     // Roots are walked from the last to the first so that the mask is built as mask + mask + take (one add-with-carry instead of
@@ -349,7 +370,13 @@ __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn
     // the `nearest` select at once - as a scalar it is copied to a vector register twice per trip
     typedef float f4v __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(3))) f4v* lds_f4;
-    const uint32_t base = (uint32_t)(uintptr_t)(lds_f4)s_roots;
+    uint32_t base = (uint32_t)(uintptr_t)(lds_f4)s_roots;
+    if (ROCT && FINITE) {
+        // the table exists once per direction octant (variant v = jn entries, v * jn * 32 bytes on; variant 0 is the plain one):
+        // the lane reads the one of its ray, whose boxes are in (near, far) order per axis (box_test_oct)
+        const uint32_t vb = (uint32_t)jn * 32u;
+        base += (oct_axis_bit(inv.x) ? vb : 0u) + (oct_axis_bit(inv.y) ? 2u * vb : 0u) + (oct_axis_bit(inv.z) ? 4u * vb : 0u);
+    }
     uint32_t at = base + (uint32_t)(jn - 1) * 32u, near_at = base - 32u;
     asm volatile("" : "+v"(at));
 #pragma nounroll
@@ -359,6 +386,7 @@ __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn
         float ta, tb;
         uint64_t m_take;
         if (!sah) m_take = lane_mask(FINITE ? box_test_finite(org, inv, lo, hi, ta, tb) : box_test(org, inv, lo, hi, ta, tb));
+        else if (FINITE && ROCT) { box_test_oct(org, inv, lo, hi, ta, tb); m_take = lane_mask(sah_widened_hit(ta, tb, hi.w, mo, mi)); }
         else if (FINITE) { box_test_finite(org, inv, lo, hi, ta, tb); m_take = lane_mask(sah_widened_hit(ta, tb, hi.w, mo, mi)); }
         else m_take = lane_mask(sah_box_test_any(org, inv, lo, hi, hi.w, mo, ta, tb));
         // a mesh without triangles: its box is all NaN (k_pack_nodes), which the min/max form can never enter; the ladder can
@@ -377,12 +405,12 @@ __device__ __forceinline__ uint32_t root_mask_loop(const float4* s_roots, int jn
     return mask;
 }
 
-template <bool STATS, int CULL>
+template <bool STATS, int CULL, bool ROCT>
 __device__ __forceinline__ uint32_t root_mask(int jn, const float4* s_roots, v3 org, v3 inv, float best_t, bool sah, Counters& cnt, int& nearest) {
     // wave-uniform choice of the slab-test form (see box_test_finite)
     const bool all_finite = lane_mask(!(__builtin_isfinite(inv.x) && __builtin_isfinite(inv.y) && __builtin_isfinite(inv.z))) == 0;
-    return all_finite ? root_mask_loop<STATS, CULL, true>(s_roots, jn, org, inv, best_t, sah, cnt, nearest)
-                      : root_mask_loop<STATS, CULL, false>(s_roots, jn, org, inv, best_t, sah, cnt, nearest);
+    return all_finite ? root_mask_loop<STATS, CULL, true, ROCT>(s_roots, jn, org, inv, best_t, sah, cnt, nearest)
+                      : root_mask_loop<STATS, CULL, false, ROCT>(s_roots, jn, org, inv, best_t, sah, cnt, nearest);
 }
 
 // SAH structure: the reference only ever tests a triangle whose leaf box IN ITS OWN TREE the ray's
@@ -492,12 +520,15 @@ __device__ __forceinline__ void fold_job(const TraceArgs* Pp, const WaveJobs* wj
     }
 }
 
-template <bool STATS, int CULL, bool FIRST_HIT, bool SAH, bool DEEP, bool MLDS>
+template <bool STATS, int CULL, bool FIRST_HIT, bool SAH, bool DEEP, bool MLDS, bool ROCT>
 __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) {
     const DevScene& S = a.scene;
     // ---- LDS: mesh root table (2 float4 per mesh), then the per-lane columns
+    // ROCT instantiations (a small SAH scene with a root table, rt_hip.hip::roct_fits): the table in its eight octant variants
+    // (box_test_oct; k_pack_nodes writes them, variant 0 first), paid for by keeping the rank -> slot table as 16-bit entries
+    static_assert(!ROCT || (SAH && !DEEP && !FIRST_HIT && !STATS), "ROCT: render kernels of small SAH scenes only");
     float4* s_roots = s_mem;
-    const int n_root4 = S.tlas_root >= 0 ? 0 : 2 * S.n_roots;
+    const int n_root4 = S.tlas_root >= 0 ? 0 : 2 * S.n_roots * (ROCT ? 8 : 1);
     for (int i = threadIdx.x; i < n_root4; i += RT_BLOCK) s_roots[i] = S.roots[i];
     // ... the mesh materials of the same scenes (80 B each): the path block reads the hit material after the winner's
     // record, a dependent memory round trip that an LDS copy shortens ...
@@ -512,11 +543,14 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     // ... and, for a small SAH scene, the rank -> slot table: the first of the path block's dependent loads (winner's
     // rank -> slot -> its records -> its material), each a round trip to the L2 otherwise
     int* s_rank = (int*)(s_mem + n_root4);
-    for (int i = threadIdx.x; i < S.rank_lds; i += RT_BLOCK) s_rank[i] = S.rank_slot[i];
+    if (ROCT) for (int i = threadIdx.x; i < S.rank_lds; i += RT_BLOCK) ((uint16_t*)s_rank)[i] = (uint16_t)S.rank_slot[i];   // (<= 2048 slots)
+    else for (int i = threadIdx.x; i < S.rank_lds; i += RT_BLOCK) s_rank[i] = S.rank_slot[i];
     // (making the LDS home of this table a compile-time fact like MLDS - ds_read instead of flat_load for the first hop of the
     // path block's dependent chain - measured +0.5 %: the block's loads are then scheduled worse; profiles/r03_k_trace_isa.txt)
     const int* rank_slot = S.rank_lds ? s_rank : S.rank_slot;
-    s_mem += (S.rank_lds + 3) / 4;
+    // (ROCT: the same either-or pointer, read as 16-bit entries - the host only picks the instantiation when the table is in LDS)
+    const auto slot_of_rank = [&](int r) { return ROCT ? (int)((const uint16_t*)rank_slot)[r] : rank_slot[r]; };
+    s_mem += ROCT ? (S.rank_lds + 7) / 8 : (S.rank_lds + 3) / 4;
     // camera and atmosphere constants: read from LDS where the path block needs them, instead of
     // ~50 scalar registers held (and spilled) across the traversal loop
     PathConsts* s_pc = (PathConsts*)(s_mem + n_root4);
@@ -805,7 +839,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                     if (tv.best_rank != RT_MISS_RANK) {
                         if (tv.best_rank < 0) id = -2 - (tv.best_rank - RT_SPHERE_RANK);
                         else {
-                            const int slot = SAH ? rank_slot[tv.best_rank] : tv.best_rank;   // (reference structure: slots are in rank order)
+                            const int slot = SAH ? slot_of_rank(tv.best_rank) : tv.best_rank;   // (reference structure: slots are in rank order)
                             id = PS.slot_id[slot];
                             if (SAH && !gated) redo = !ref_leaf_box_passes(PS, slot, org, inv) || P.recheck_all != 0;
                         }
@@ -834,7 +868,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         normal = normalize3(hit_point - V3(sph.position[0], sph.position[1], sph.position[2]));
                         hit_mat = 256 + si;
                     } else {
-                        const int slot = SAH ? rank_slot[tv.best_rank] : tv.best_rank;
+                        const int slot = SAH ? slot_of_rank(tv.best_rank) : tv.best_rank;
                         const float4* g = S.tri_geo + 4 * (size_t)slot;
                         const float4 g0 = g[0], g1 = g[1], g2 = g[2];
                         const v3 A = V3(g0.x, g0.y, g0.z), B = V3(g1.x, g1.y, g1.z), C = V3(g2.x, g2.y, g2.z);
@@ -863,7 +897,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         // lies inside every box any structure over the same triangles puts the triangle in, and float
                         // subtract / multiply are monotonic, so its interval lies inside theirs: no flagged query means no
                         // culling traversal of either structure can lose the reference's winner on this launch's rays.
-                        const int slot = SAH ? rank_slot[tv.best_rank] : tv.best_rank;
+                        const int slot = SAH ? slot_of_rank(tv.best_rank) : tv.best_rank;
                         const float4* g = S.tri_geo + 4 * (size_t)slot;
                         const float4 a0 = g[0], a1 = g[1], a2 = g[2];
                         const float4 lo = make_float4(__builtin_fminf(a0.x, __builtin_fminf(a1.x, a2.x)), __builtin_fminf(a0.y, __builtin_fminf(a1.y, a2.y)),
@@ -1087,7 +1121,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 } else {
                     tv.cur = RT_NONE;
                     int nearest;
-                    tv.mask = root_mask<STATS, CULL>(__builtin_amdgcn_readfirstlane(PS.n_roots), s_roots, org, inv, tv.best_t, sah, cnt, nearest);
+                    tv.mask = root_mask<STATS, CULL, ROCT>(__builtin_amdgcn_readfirstlane(PS.n_roots), s_roots, org, inv, tv.best_t, sah, cnt, nearest);
                     // the mesh whose root box the ray enters first is visited first (a hit there culls the others)
                     // (entry distances of +inf / NaN leave `nearest` unset: then the first root of the mask; roots are interior records)
                     if (tv.mask) {

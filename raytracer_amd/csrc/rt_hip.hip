@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_ref_leaf_boxes(const int* leaf_off, con
 }
 
 __global__ __launch_bounds__(256) void k_pack_nodes(const PackInfo* pi, int n_rec, const float4* nbox, float4* nodes,
-                                                    const int* root_v, const int* root_ref, int n_meshes, float4* roots, int pad) {
+                                                    const int* root_v, const int* root_ref, int n_meshes, float4* roots, int pad, int root_variants) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_rec) {
         PackInfo p = pi[i];
@@ -233,6 +233,16 @@ __global__ __launch_bounds__(256) void k_pack_nodes(const PackInfo* pi, int n_re
         lo.w = __int_as_float(dev_ref(root_ref[i]));
         roots[2 * i] = lo;
         roots[2 * i + 1] = hi;
+        // root_variants = 8: the table once per direction octant, variant v at entry v * n_meshes: axis a in (hi, lo) = (near, far)
+        // order where bit a of v is set (rt_dev_trace.h::box_test_oct); reference and slack stay where they are
+        for (int v = 1; v < root_variants; v++) {
+            float4 a = lo, b = hi;
+            if (v & 1) { a.x = hi.x; b.x = lo.x; }
+            if (v & 2) { a.y = hi.y; b.y = lo.y; }
+            if (v & 4) { a.z = hi.z; b.z = lo.z; }
+            roots[2 * ((size_t)v * n_meshes + i)] = a;
+            roots[2 * ((size_t)v * n_meshes + i) + 1] = b;
+        }
     }
 }
 
@@ -256,10 +266,10 @@ __global__ __launch_bounds__(256) void k_gather_tris28(const float4* geo, const 
 #ifndef RT_WAVES
 #define RT_WAVES 5
 #endif
-template <bool STATS, int CULL, bool FIRST_HIT, bool SAH, bool DEEP, bool MLDS>
+template <bool STATS, int CULL, bool FIRST_HIT, bool SAH, bool DEEP, bool MLDS, bool ROCT>
 __global__ __launch_bounds__(RT_BLOCK, RT_WAVES) void k_trace(TraceArgs a) {
     extern __shared__ float4 s_mem[];
-    trace_pixels<STATS, CULL, FIRST_HIT, SAH, DEEP, MLDS>(a, s_mem);
+    trace_pixels<STATS, CULL, FIRST_HIT, SAH, DEEP, MLDS, ROCT>(a, s_mem);
 }
 
 // Scratch of rt_render_static, the entry point that allocates nothing (include/rt_hip.h): the work
@@ -451,6 +461,7 @@ struct rt_ctx {
     MatDev* h_mats_pinned = nullptr;      // rt_set_materials: pinned staging of the 256 materials, guarded by mats_copied
     hipEvent_t mats_copied = nullptr;
     uint32_t max_cycles = 0xffffffffu;    // passes with a larger index leave the image as it is (raytracer.fs.glsl:931-935)
+    int last_root_variants = 0;
     int last_stack_lds = 0, last_lds_bytes = 0, last_blocks_per_cu = 0;   // layout of the most recent k_trace launch (rt_get_info)
     int tlas_rebuilds = 0;
     int stack_lds_force = 0;              // RT_STACK_LDS: LDS node stack entries, whatever the occupancy (tests of the deep-entry path)
@@ -469,6 +480,8 @@ struct rt_ctx {
     MatDev atmo{};
     int n_tris = 0, n_slots = 0, n_meshes = 0, n_nodes = 0, n_visit = 0, n_rec = 0, n_spheres = 0;
     int n_roots = 0;                      // entries of the root table: one per mesh, or per group of meshes (SAH structure, sah_group_below)
+    bool root_oct = false;                // the root table of the scene in place exists in its eight octant variants (ROCT instantiations of k_trace)
+    bool root_oct_allowed = true;         // RT_ROOT_OCT=0: never
     int treelet = 8;                      // RT_TREELET: interior records laid out in breadth-first blocks of this many (0 = depth-first order)
     bool sah_tip_pad = true;              // RT_SAH_TIP_PAD=0: the SAH boxes' slack without the sliver-tip pad (tests: what the pad is for)
     int sah_group_below = 0;              // RT_SAH_GROUP_BELOW: meshes with fewer triangles share one SAH tree (0 = one tree per mesh)
@@ -629,7 +642,7 @@ int run_prep(rt_ctx* c) {
     size_t m = (size_t)std::max(c->n_rec, c->n_roots);
     if (m)
         hipLaunchKernelGGL(k_pack_nodes, dim3(blocks_for(m)), dim3(256), 0, c->stream, c->pack.p, c->n_rec, c->nbox.p,
-                           c->nodes.p, c->root_v.p, c->root_ref.p, c->n_roots, c->roots.p, c->scene_is_sah ? 1 : 0);
+                           c->nodes.p, c->root_v.p, c->root_ref.p, c->n_roots, c->roots.p, c->scene_is_sah ? 1 : 0, c->root_oct ? 8 : 1);
     HIPCK(c, hipGetLastError());
     for (auto& d : c->h_dirty) d = 0;
     c->prep_pending = false;
@@ -693,33 +706,35 @@ int rank_lds_entries(const rt_ctx* c) {
     return (c->scene_is_sah && c->tlas_root < 0 && c->n_slots <= 2048) ? c->n_slots : 0;
 }
 
-size_t trace_lds_bytes(const rt_ctx* c, int cap, bool cull, bool sah, bool deep) {
-    const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_roots + 5 * c->n_meshes) + (size_t)(rank_lds_entries(c) + 3) / 4 + RT_PC_F4) * sizeof(float4);   // roots, materials, rank table, arguments
+size_t trace_lds_bytes(const rt_ctx* c, int cap, bool cull, bool sah, bool deep, bool roct = false) {
+    // (roct: the root table eight times, the rank table as 16-bit entries - the ROCT instantiations' layout, rt_dev_trace.h)
+    const size_t fixed = ((size_t)(c->tlas_root >= 0 ? 0 : 2 * c->n_roots * (roct ? 8 : 1) + 5 * c->n_meshes) +
+                          (size_t)(roct ? (rank_lds_entries(c) + 7) / 8 : (rank_lds_entries(c) + 3) / 4) + RT_PC_F4) * sizeof(float4);   // roots, materials, rank table, arguments
     const size_t lq = RT_LQ_OF(sah);
     if (RT_LQ64_OF(sah, cull, deep)) return fixed + ((size_t)cap * 4 + lq * 8) * RT_BLOCK;      // 8-byte leaf queue entries (rt_dev_trace.h)
     return fixed + ((size_t)cap + lq) * RT_BLOCK * 4 + (cull ? lq * RT_BLOCK * 2 : 0);
 }
 
-template <bool STATS, int CULL, bool FIRST, bool SAH, bool DEEP, bool MLDS>
+template <bool STATS, int CULL, bool FIRST, bool SAH, bool DEEP, bool MLDS, bool ROCT = false>
 int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     if (c->blocks_per_cu[key] <= 0) {
         int nb = 0, nb_best = 0;
         for (;;) {
-            HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS>, RT_BLOCK, trace_lds_bytes(c, cap, CULL, SAH, DEEP)));
+            HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS, ROCT>, RT_BLOCK, trace_lds_bytes(c, cap, CULL, SAH, DEEP, ROCT)));
             if (!DEEP || nb >= RT_WAVES || cap <= RT_MIN_STACK_LDS || c->stack_lds_force > 0) break;
             // lds_stack_entries guessed the allocation granule wrong, or registers are the limit
             if (nb_best == 0)
-                HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_best, k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS>, RT_BLOCK, trace_lds_bytes(c, RT_MIN_STACK_LDS, CULL, SAH, DEEP)));
+                HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_best, k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS, ROCT>, RT_BLOCK, trace_lds_bytes(c, RT_MIN_STACK_LDS, CULL, SAH, DEEP, ROCT)));
             if (nb >= nb_best) break;
             cap--;
         }
-        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (%d roots, %d meshes)", trace_lds_bytes(c, cap, CULL, SAH, DEEP), c->n_roots, c->n_meshes);
+        if (nb < 1) return fail(c, RT_E_LIMIT, "scene needs %zu bytes of LDS per workgroup (%d roots, %d meshes)", trace_lds_bytes(c, cap, CULL, SAH, DEEP, ROCT), c->n_roots, c->n_meshes);
         c->blocks_per_cu[key] = nb;
         c->stack_lds[key] = cap;
-        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] k_trace variant %d: %d of %d node stack entries in LDS, %zu bytes of LDS, %d workgroups per CU\n", key, cap, c->stack_depth, trace_lds_bytes(c, cap, CULL, SAH, DEEP), nb);
+        if (getenv("RT_DEBUG")) fprintf(stderr, "[rt] k_trace variant %d: %d of %d node stack entries in LDS, %zu bytes of LDS, %d workgroups per CU\n", key, cap, c->stack_depth, trace_lds_bytes(c, cap, CULL, SAH, DEEP, ROCT), nb);
     }
     cap = c->stack_lds[key];
-    const size_t lds = trace_lds_bytes(c, cap, CULL, SAH, DEEP);
+    const size_t lds = trace_lds_bytes(c, cap, CULL, SAH, DEEP, ROCT);
     // every wave takes whole chunks: no point in more waves than chunks
     unsigned grid = std::max(1u, (unsigned)std::min<uint64_t>((uint64_t)c->blocks_per_cu[key] * c->n_cus, ((uint64_t)a.n_jobs + 3) / 4));
     TraceArgs b = a;
@@ -761,8 +776,9 @@ int launch_one(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     c->last_stack_lds = cap;
     c->last_lds_bytes = (int)lds;
     c->last_blocks_per_cu = c->blocks_per_cu[key];
+    c->last_root_variants = c->tlas_root >= 0 ? 0 : ROCT ? 8 : 1;
     HIPCK(c, hipMemsetAsync(b.work_counter, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS>), dim3(grid), dim3(RT_BLOCK), lds, c->stream, b);
+    hipLaunchKernelGGL((k_trace<STATS, CULL, FIRST, SAH, DEEP, MLDS, ROCT>), dim3(grid), dim3(RT_BLOCK), lds, c->stream, b);
     return RT_OK;
 }
 
@@ -785,7 +801,15 @@ int launch_mats(rt_ctx* c, const TraceArgs& a, int key, int cap) {
     // MLDS: the materials of every possible hit are in k_trace's LDS copy (a scene with a root table, i.e. without a top-level
     // tree, and without spheres) - proved here on the host, per launch.  Only the render kernels have the instantiation.
     if constexpr (!STATS && !FIRST) {
-        if (c->tlas_root < 0 && c->n_spheres == 0 && c->n_meshes > 0) return launch_one<STATS, CULL, FIRST, SAH, DEEP, true>(c, a, key, cap);
+        if (c->tlas_root < 0 && c->n_spheres == 0 && c->n_meshes > 0) {
+            // ROCT: the root table in its eight octant variants (rt_set_scene wrote them: root_oct) where that layout fits the LDS
+            // of a full-occupancy launch with the whole node stack, like the plain one does (!DEEP)
+            if constexpr (SAH && !DEEP) {
+                if (c->root_oct && cap == c->stack_depth && trace_lds_bytes(c, cap, CULL, SAH, DEEP, true) <= (c->lds_per_cu / RT_WAVES) / 1280 * 1280)
+                    return launch_one<STATS, CULL, FIRST, SAH, DEEP, true, true>(c, a, key, cap);
+            }
+            return launch_one<STATS, CULL, FIRST, SAH, DEEP, true>(c, a, key, cap);
+        }
     }
     return launch_one<STATS, CULL, FIRST, SAH, DEEP, false>(c, a, key, cap);
 }
@@ -895,6 +919,7 @@ int rt_create(int device, rt_ctx** out) {
     if (const char* e = getenv("RT_SAH_GROUP_BELOW")) c->sah_group_below = std::max(0, atoi(e));
     if (const char* e = getenv("RT_SAH_TIP_PAD")) c->sah_tip_pad = atoi(e) != 0;
     if (const char* e = getenv("RT_TREELET")) c->treelet = std::max(0, atoi(e));
+    if (const char* e = getenv("RT_ROOT_OCT")) c->root_oct_allowed = atoi(e) != 0;
     if (const char* e = getenv("RT_TLAS_STATIC")) c->tlas_static = atoi(e) != 0;
     if (const char* e = getenv("RT_TLAS_ABOVE")) c->tlas_above = std::max(1, std::min(32, atoi(e)));
     if (const char* e = getenv("RT_NODE_BIAS")) c->node_bias = atoi(e);
@@ -1271,7 +1296,10 @@ int rt_set_scene(rt_ctx* c, const float* tris28, int n_tris, const void* meshes1
     HIPCK(c, c->geo.alloc(4 * (size_t)c->n_slots));
     HIPCK(c, c->nrm.alloc(4 * (size_t)c->n_slots));
     HIPCK(c, c->nodes.alloc(4 * (size_t)c->n_rec));
-    HIPCK(c, c->roots.alloc(2 * (size_t)c->n_roots));
+    // a small SAH scene with a root table gets the table in its eight octant variants (box_test_oct): the condition under which
+    // k_trace keeps the rank -> slot table in LDS, where 16-bit entries make the room (rank_lds_entries, trace_lds_bytes)
+    c->root_oct = c->root_oct_allowed && sah && tlas_root < 0 && c->n_roots > 0 && c->n_slots <= 2048;
+    HIPCK(c, c->roots.alloc(2 * (size_t)c->n_roots * (c->root_oct ? 8 : 1)));
     HIPCK(c, c->nbox.alloc(2 * (size_t)c->n_visit));
     HIPCK(c, c->xf.alloc(16 * (size_t)std::max(n_meshes, 1)));
     HIPCK(c, c->dirty.alloc((size_t)std::max(n_meshes, 1)));
@@ -1632,6 +1660,7 @@ int rt_get_info(rt_ctx* c, rt_info_t* o) {
     o->workgroups_per_cu = c->last_blocks_per_cu;
     o->top_level_rebuilds = c->tlas_rebuilds;
     o->n_roots = c->n_roots;
+    o->root_table_variants = c->last_root_variants;
     return RT_OK;
 }
 

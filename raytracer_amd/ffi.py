@@ -40,7 +40,7 @@ class RtStats(C.Structure):
 
 class RtInfo(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("accel", "n_slots", "n_records", "top_level_tree", "stack_entries", "stack_entries_lds",
-                                         "lds_bytes", "workgroups_per_cu", "top_level_rebuilds", "n_roots")] + [("reserved", C.c_int32 * 6)]
+                                         "lds_bytes", "workgroups_per_cu", "top_level_rebuilds", "n_roots", "root_table_variants")] + [("reserved", C.c_int32 * 5)]
 
     def as_dict(self) -> dict:
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -106,3 +106,46 @@ def test_sah_repeat_path_gives_the_same_image(hip_lib, monkeypatch):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
         assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
         assert a[3]["rays"] == b[3]["rays"] and a[3]["shaded_hits"] == b[3]["shaded_hits"]
+
+
+@pytest.mark.gpu
+def test_root_table_octant_variants_same_image(hip_lib, oracle_lib):
+    """Small SAH scenes keep their root table once per direction octant, every box in (near, far) order per axis, so that the
+    root loop needs no min / max (rt_dev_trace.h::box_test_oct; the ROCT instantiations of k_trace).  The entry / exit values are
+    the same numbers, so the image must be the one without the variants (RT_ROOT_OCT=0) - and the oracle's - bit for bit, in
+    every culling mode; info() says which table the launch read."""
+    w, h = 320, 180
+    sc = build_suzanne(0)
+    o = oracle_lib.create()
+    o.load_scene(sc)
+    o.load_camera(sc.cam)
+    o.resize(w, h)
+    o.render(1, 3, 1, 2, 6, 0)
+    want = o.read_mean().view(np.uint32)
+    old = os.environ.get("RT_ROOT_OCT")
+    try:
+        for cull in (0, 1, 2):
+            got = {}
+            for flag in ("0", "1"):
+                os.environ["RT_ROOT_OCT"] = flag             # read by rt_create
+                c = _ctx(hip_lib, build_suzanne(0), w, h, True, cull)
+                c.render(1, 3, 1, 2, 6, 0)
+                got[flag] = c.read_mean().view(np.uint32)
+                assert c.info()["root_table_variants"] == (8 if flag == "1" else 1), c.info()
+                c.close()
+            assert np.array_equal(got["0"], got["1"]), f"cull mode {cull}: the octant table changes the image"
+            assert np.array_equal(got["1"], want), f"cull mode {cull}: differs from the oracle"
+    finally:
+        if old is None:
+            os.environ.pop("RT_ROOT_OCT", None)
+        else:
+            os.environ["RT_ROOT_OCT"] = old
+    # a scene with analytic spheres, or on the reference's structure, has no such instantiation: the plain table
+    c = _ctx(hip_lib, random_scene(3), 64, 36, True, 1)
+    c.render(1, 1, 1, 1, 2, 0)
+    assert c.info()["root_table_variants"] in (0, 1)
+    c.close()
+    c = _ctx(hip_lib, build_suzanne(0), 64, 36, False, 1)
+    c.render(1, 1, 1, 1, 2, 0)
+    assert c.info()["root_table_variants"] == 1
+    c.close()

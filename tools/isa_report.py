@@ -13,7 +13,7 @@ import tempfile
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-NAME = sys.argv[1] if len(sys.argv) > 1 else "_Z7k_traceILb0ELi1ELb0ELb1ELb0ELb1EEv9TraceArgs"   # <STATS=0, CULL=1, FIRST_HIT=0, SAH=1, DEEP=0, MLDS=1>
+NAME = sys.argv[1] if len(sys.argv) > 1 else "_Z7k_traceILb0ELi1ELb0ELb1ELb0ELb1ELb1EEv9TraceArgs"   # <STATS=0, CULL=1, FIRST_HIT=0, SAH=1, DEEP=0, MLDS=1, ROCT=1>
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-DRT_WAVES=6"]
 
 with tempfile.TemporaryDirectory() as tmp:
