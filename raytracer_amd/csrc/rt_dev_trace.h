@@ -234,9 +234,48 @@ __device__ __forceinline__ bool sah_box_test_any(v3 o, v3 inv, float4 lo, float4
     return box_test(o, inv, make_float4(lo.x - e, lo.y - e, lo.z - e, 0.f), make_float4(hi.x + e, hi.y + e, hi.z + e, 0.f), tmin_out, tmax_out);
 }
 
+// Calibration (timing experiments only, profiles/r03_k_trace_isa.txt): N dummy instructions at the END of a block - what one more
+// vector / scalar instruction costs THERE.  -DRT_CAL_NODE_VALU=8, -DRT_CAL_NODE_SALU=16, -DRT_CAL_TRI_VALU=8, -DRT_CAL_PATH_VALU=64
+template <int N>
+__device__ __forceinline__ void cal_valu() {
+    if (N > 0) {
+        float d = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; i++) asm volatile("v_max_f32 %0, %0, %0" : "+v"(d));
+    }
+}
+template <int N>
+__device__ __forceinline__ void cal_salu() {
+    if (N > 0) {
+        int d = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(d) : : "scc");
+    }
+}
+#ifndef RT_CAL_NODE_VALU
+#define RT_CAL_NODE_VALU 0
+#endif
+#ifndef RT_CAL_NODE_SALU
+#define RT_CAL_NODE_SALU 0
+#endif
+#ifndef RT_CAL_TRI_VALU
+#define RT_CAL_TRI_VALU 0
+#endif
+#ifndef RT_CAL_PATH_VALU
+#define RT_CAL_PATH_VALU 0
+#endif
+
 // A per-lane boolean as the wave's 64-bit lane mask and back: logic on masks runs on the scalar unit
 __device__ __forceinline__ uint64_t lane_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ __forceinline__ bool in_mask(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// lanes in a mask, as a 32-bit scalar the compiler knows nothing about: it widens the compare of two __builtin_popcountll results
+// to 64 bits, for which the scalar unit has no ordered compare - and issues a VECTOR compare in the middle of the vote
+__device__ __forceinline__ int lanes_in(uint64_t m) {
+    int c;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(c) : "s"(m) : "scc");
+    return c;
+}
 
 // 2 m + b as ONE vector instruction (add with carry-in from the lane mask of b); the compiler's own form is select + shift-or
 __device__ __forceinline__ uint32_t shl1_add(uint32_t m, uint64_t lanes_of_b) {
@@ -657,7 +696,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
     // waiting for the path block.  A lane whose query finishes inside the loop is marked in m_fin (scalar logic on masks the
     // vote computes anyway); its `mode` register is brought up to date once, when the loop is left - a compare and a select
     // fewer in every trip of the vote.
-    uint64_t m_trav = 0, m_path = ~0ull, m_fin = 0;
+    uint64_t m_trav = 0, m_path = ~0ull, m_fin = 0, m_pw = ~0ull;
     uint64_t m_k = 0;          // lanes with a triangle in progress (tv.k >= 0): changes in triangle steps and at a query's start only
 
     while (true) {
@@ -667,10 +706,20 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
             const uint64_t bN = m_live & lane_mask(lq_room_for_two(tv.lq));             // can take a node step
             const bool can_node = in_mask(bN);
             m_fin = m_trav & ~bT & ~m_live;                                             // the query is finished
-            const int cN = __popcll(bN), cT = __popcll(bT), cAny = __popcll(bN | bT);
-            if (cAny == 0) break;
-            if (cAny < a.refill_below && (m_fin | m_path) != 0) break;
-            const bool do_node = cT == 0 || (cN > 0 && cN + a.node_bias > cT);   // never a step without lanes
+            // The vote runs once per node step / triangle burst on the scalar unit, and a scalar instruction of this loop costs the
+            // frame 1.5 x what a vector one does (profiles/r03_k_trace_isa.txt, calibration), so it is written for the scalar unit:
+            // ONE way out of the loop - "fewer than refill_below lanes traverse and some lane waits for the path block", where "no
+            // lane traverses" is the case 0 < refill_below (m_pw: all ones when no query is in flight at all, else the lanes waiting
+            // since the last path block; with queries in flight and none left to step, m_fin is not empty) - as one select and one
+            // compare; and without a bias a node step is taken when cN > cT (lanes exist, so cT == 0 implies cN > 0).
+            const int cAny = lanes_in(bN | bT), cGo = (m_fin | m_pw) != 0 ? cAny : 64;
+            if (cGo < a.refill_below) break;
+            const int cN = lanes_in(bN), cT = lanes_in(bT);
+#ifdef RT_NODE_BIAS_KNOB    // sweeps only (tools/sweep_sched.sh; measured flat within +-8 lanes, worse beyond): a step never runs without lanes
+            const bool do_node = (cN ? cN + a.node_bias : -(1 << 20)) > (cT ? cT : -(1 << 30));
+#else
+            const bool do_node = cN > cT;
+#endif
             if (STATS && do_node) { sch.node_steps++; sch.node_lanes += cN; }
             if (do_node) {
                 if (can_node) {
@@ -691,7 +740,10 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                         // (k_pack_nodes): in the min/max form every slab value, hence the interval, is NaN, and NaN <= x is false -
                         // the test fails by itself, no compare of the reference needed (two vector instructions per node step: -0.9 %).
                         // The compare ladder reads NaN as "not disjoint" (as the reference does), so those branches do test it.
-                        if ((m_nonfinite & lane_mask(true)) == 0) {
+                        // (m_nonfinite holds the lanes with a query in flight only, so the whole mask is tested: a compare and a branch;
+                        // a lane outside this step can send the step down the ladder, which is exact for every ray.  The hot path
+                        // falls through: two taken branches fewer.)
+                        if (__builtin_expect(m_nonfinite == 0, 1)) {
                             box_test_finite(org, inv, n0, n1, t1a, t1b);
                             box_test_finite(org, inv, n2, n3, t2a, t2b);
                             if (sah) {
@@ -721,26 +773,27 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             }
                         }
                         if (STATS) cnt.box += (ref1 != RT_NONE) + (ref2 != RT_NONE);
-                        const uint64_t m_sn = lane_mask(t2a < t1a);   // far child first, so that the near one is taken up first
-                        const uint64_t m_l1 = lane_mask(ref1 < 0), m_l2 = lane_mask(ref2 < 0);
-                        const uint64_t m_hn = (m_sn & m_h2) | (~m_sn & m_h1), m_hf = (m_sn & m_h1) | (~m_sn & m_h2);
-                        const uint64_t m_ln = (m_sn & m_l2) | (~m_sn & m_l1), m_lf = (m_sn & m_l1) | (~m_sn & m_l2);
-                        const bool second_near = in_mask(m_sn);
-                        const int rn = second_near ? ref2 : ref1, rf = second_near ? ref1 : ref2;
+                        // Far child first, so that the near one is taken up first.  A child that is missed or culled becomes "no
+                        // record" BEFORE the two are ordered, and what each ordered child is - a leaf (reference above 0x80000000
+                        // as unsigned), an interior record (>= 0) or nothing - is read off its reference with one compare: the
+                        // same decisions as lane-mask algebra on (hit, leaf, nearer) cost fourteen scalar instructions per step,
+                        // and a scalar instruction of this loop costs more than a vector one (profiles/r03_k_trace_isa.txt).
+                        const bool second_near = t2a < t1a;
+                        const int r1 = in_mask(m_h1) ? ref1 : RT_NONE, r2 = in_mask(m_h2) ? ref2 : RT_NONE;
+                        const int rn = second_near ? r2 : r1, rf = second_near ? r1 : r2;
                         const float tn = second_near ? t2a : t1a, tf = second_near ? t1a : t2a;
-                        if (in_mask(m_hf & m_lf)) {
+                        if ((uint32_t)rf > (uint32_t)RT_NONE) {
                             lq_push(tv.lq, rf, tf);
                         }
-                        if (in_mask(m_hn & m_ln)) {
+                        if ((uint32_t)rn > (uint32_t)RT_NONE) {
                             lq_push(tv.lq, rn, tn);
                         }
-                        const uint64_t m_in = m_hn & ~m_ln, m_if = m_hf & ~m_lf;
-                        if (in_mask(m_in & m_if)) {
+                        if ((rn | rf) >= 0) {                       // both interior: the far one waits on the node stack
                             if (!DEEP || tv.sp + (int)ST_PLANE < (int)st_lim) *(lds_i)(uintptr_t)((uint32_t)tv.sp + ST_PLANE) = rf;
                             else *(int*)(ovf_base + (uint32_t)(tv.sp + (int)ST_PLANE)) = rf;
                             bump_in_place<ST_PLANE>(tv.sp);
                         }
-                        tv.cur = in_mask(m_in) ? rn : (in_mask(m_if) ? rf : RT_NONE);
+                        tv.cur = rn >= 0 ? rn : (rf >= 0 ? rf : RT_NONE);
                         // ---- no child to go on with: take up the next record NOW (a deferred far child, else the next mesh root),
                         // so that between steps "node work remains" is simply "a record is in hand" ----
                         if (tv.cur == RT_NONE) {
@@ -755,6 +808,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 tv.cur = __float_as_int(s_roots[2 * b].w);
                             }
                         }
+                        cal_valu<RT_CAL_NODE_VALU>();
+                        cal_salu<RT_CAL_NODE_SALU>();
                     }
                 }
                 m_live &= ~(bN & lane_mask(tv.cur == RT_NONE));
@@ -762,7 +817,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 // triangle burst: stay on triangles while at least half of the lanes that were
                 // traversing at the vote still have leaf work (an upper bound of the lanes a node
                 // step could serve then outnumbers them and the full vote is taken again)
-                const int lim = cN + cT;
+                const int lim = max(a.burst8 * (cN + cT), 1);           // (>= 1: a step never runs without lanes)
                 int cTn;
                 uint64_t m_leaf = bT;                                   // lanes with leaf work: the vote's mask, then each step's own
                 do {
@@ -809,20 +864,20 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                                 // SAH structure, a query that is being repeated (see the path block): a hit
                                 // counts only if the ray passes the box of the triangle's leaf in the
                                 // REFERENCE's tree
-                                const uint64_t m_chk = SAH ? m_gated & lane_mask(inside) : 0;
-                                if (SAH && m_chk != 0) {
-                                    if (in_mask(m_chk)) inside = ref_leaf_box_passes(S, (int)((uint32_t)tv.k >> 6), org, inv);
+                                if (SAH && m_gated != 0) {                  // (wave-level: rare, one compare and one branch)
+                                    if (in_mask(m_gated & lane_mask(inside))) inside = ref_leaf_box_passes(S, (int)((uint32_t)tv.k >> 6), org, inv);
                                 }
                                 tv.best_t = inside ? t : tv.best_t;
                                 tv.best_rank = inside ? rank_k : tv.best_rank;
                             }
                             tv.k = __float_as_int(g3.y);                    // the leaf's next slot, or -1
+                            cal_valu<RT_CAL_TRI_VALU>();
                         }
                     }
                     m_k = lane_mask(tv.k >= 0);
                     m_leaf = m_k | lane_mask(lq_nonempty(tv.lq));
-                    cTn = __popcll(m_leaf);
-                } while (cTn > 0 && 8 * cTn >= a.burst8 * lim);
+                    cTn = lanes_in(m_leaf);
+                } while (8 * cTn >= lim);
             }
         }
         if (in_mask(m_fin)) mode = M_PATH;
@@ -1089,6 +1144,7 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 }
             }
             if (start) {                                           // begin one closest-hit query (:518-541)
+                cal_valu<RT_CAL_PATH_VALU>();
                 if (STATS) cnt.rays += !redo;
                 gated = redo;
                 inv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
@@ -1136,13 +1192,14 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
         __builtin_amdgcn_s_setprio(RT_PRIO_TRAV);
         // The wave is converged here: take the two lane masks anew, for the queries that have just started and (to the
         // same values: node work remains <=> a record in hand, a deferred one or a root left) for those still in flight.
-        // A lane without a query keeps the 1/d of its last one; its bit in m_nonfinite is never looked at.
+        // (a lane without a query keeps the 1/d of its last one: masked out of m_nonfinite)
         m_trav = lane_mask(mode == M_TRAV);
         m_k = lane_mask(tv.k >= 0);
         m_path = lane_mask(mode == M_PATH);
+        m_pw = m_trav ? m_path : ~0ull;
         m_live = m_trav & lane_mask(tv.cur != RT_NONE);
         m_gated = SAH ? lane_mask(gated) : 0;
-        m_nonfinite = ~(lane_mask(__builtin_isfinite(inv.x)) & lane_mask(__builtin_isfinite(inv.y)) & lane_mask(__builtin_isfinite(inv.z)));
+        m_nonfinite = m_trav & ~(lane_mask(__builtin_isfinite(inv.x)) & lane_mask(__builtin_isfinite(inv.y)) & lane_mask(__builtin_isfinite(inv.z)));
     }
     if (!FIRST_HIT) {
         // every job was folded when its last sample finished (the lane that finishes it asks for the next sample in
