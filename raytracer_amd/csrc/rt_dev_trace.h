@@ -822,8 +822,10 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                 uint64_t m_leaf = bT;                                   // lanes with leaf work: the vote's mask, then each step's own
                 do {
                     if (STATS) { sch.tri_steps++; sch.tri_lanes += __popcll(m_leaf); }
-                    if (in_mask(m_leaf)) {
-                        if (tv.k < 0) {                                 // take up the most recently found leaf
+                    {
+                        // (no region around the lanes with leaf work: the two conditions below are false for every other lane - m_leaf is
+                        // "a triangle in progress or a queued leaf" - and a region costs three scalar instructions per step)
+                        if (in_mask(m_leaf & ~m_k)) {                   // take up the most recently found leaf
                             const float beyond = fma_(tv.best_t, RT_CULL_REL, tv.best_t) + RT_CULL_ABS;
                             if (LQ64) {
                                 const i2v e = *(lds_i2)(uintptr_t)(uint32_t)tv.lq;
@@ -854,7 +856,8 @@ __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) 
                             bool ok = tested && !(__builtin_fabsf(nd) < 1e-6f) && !(nd > 0.0f && !hb);
                             ok = ok && !(t < 1e-6f);                        // covers the reference's `t < 0` reject too
                             // closer than (or tied with a later-ranked) current best; NaN t never wins
-                            ok = ok && (t < tv.best_t || (t == tv.best_t && rank_k < tv.best_rank));
+                            // (as lane masks: the short-circuit form is a divergent region of its own, seven scalar instructions)
+                            ok = ok && in_mask(lane_mask(t < tv.best_t) | (lane_mask(t == tv.best_t) & lane_mask(rank_k < tv.best_rank)));
                             if (ok) {
                                 const v3 P = madd3(org, t, dir);
                                 const float e0 = dot3(N, cross3(B - A, P - A));
