@@ -686,7 +686,9 @@ void fill_args(const rt_ctx* c, TraceArgs& a) {
     a.tile_lx = a.tile_ly = 0;
     a.job_cap = 0;
     a.node_bias = c->node_bias;
-    a.burst8 = c->burst8 >= 0 ? c->burst8 : (c->scene_is_sah ? 3 : 4);
+    // (SAH scenes: 3 of 8 with a top-level tree or beyond the L2, 4 of 8 for the root-table scenes since the vote got cheaper -
+    // re-swept on the final kernel of round 3: 39.40 -> 39.30 ms on the bench frame, the other two flat)
+    a.burst8 = c->burst8 >= 0 ? c->burst8 : (c->scene_is_sah && (c->tlas_root >= 0 || c->n_slots > 100000) ? 3 : 4);
     a.recheck_all = c->recheck_all;
     // best measured (tools/sweep_sched.sh): a scene that lives in the L2 gains from shading fuller path blocks,
     // one that does not (991 k triangles) from refilling earlier (28 since round 3: tools/sweep_inproc.py); a scene with a top-level tree (long traversals) shades fuller still;
