@@ -357,7 +357,7 @@ struct TraceArgs {
     int rays_per_pixel, max_bounces, sum_mode;
     int recheck_all;              // SAH, tests only: repeat every query that hit a triangle with the per-hit check on
     int refill_below;             // traversal yields to the path block when fewer lanes than this traverse
-    int node_bias;                // a node step is taken when cN + node_bias > cT
+    int node_bias;                // builds with -DRT_NODE_BIAS_KNOB only: a node step is taken when cN + node_bias > cT (default vote: cN > cT)
     int burst8;                   // a triangle burst lasts while 8 * (lanes with leaf work) >= burst8 * (lanes traversing at the vote)
 };
 
