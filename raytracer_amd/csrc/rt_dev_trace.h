@@ -563,7 +563,7 @@ template <bool STATS, int CULL, bool FIRST_HIT, bool SAH, bool DEEP, bool MLDS, 
 __device__ __forceinline__ void trace_pixels(const TraceArgs& a, float4* s_mem) {
     const DevScene& S = a.scene;
     // ---- LDS: mesh root table (2 float4 per mesh), then the per-lane columns
-    // ROCT instantiations (a small SAH scene with a root table, rt_hip.hip::roct_fits): the table in its eight octant variants
+    // ROCT instantiations (a small SAH scene with a root table; chosen per launch in rt_hip.hip::launch_mats where the layout fits): the table in its eight octant variants
     // (box_test_oct; k_pack_nodes writes them, variant 0 first), paid for by keeping the rank -> slot table as 16-bit entries
     static_assert(!ROCT || (SAH && !DEEP && !FIRST_HIT && !STATS), "ROCT: render kernels of small SAH scenes only");
     float4* s_roots = s_mem;
