@@ -42,3 +42,28 @@ def test_product_has_no_cpu_fallback(tmp_path):
         if f.suffix in (".py", ".hip", ".h"):
             text = f.read_text()
             assert "librt_oracle" not in text and "np_ref" not in text and "import oracle" not in text, f
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """rt_stats_t / rt_info_t as gcc lays them out from include/rt_hip.h == the ctypes structures of the binding, size and
+    every field offset (a field added to one side only would shift everything after it)."""
+    import subprocess
+
+    from raytracer_amd import ffi
+
+    fields = {"rt_stats_t": [k for k, _ in ffi.RtStats._fields_], "rt_info_t": [k for k, _ in ffi.RtInfo._fields_]}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rt_hip.h"', "int main(void) {"]
+    for name, fs in fields.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for f in fs:
+            lines.append(f'  printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", str(ROOT / "include"), str(src), "-o", str(exe)])
+    got = dict(ln.split() for ln in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name, cls in (("rt_stats_t", ffi.RtStats), ("rt_info_t", ffi.RtInfo)):
+        assert int(got[name]) == ctypes.sizeof(cls), name
+        for f in fields[name]:
+            assert int(got[f"{name}.{f}"]) == getattr(cls, f).offset, f"{name}.{f}"
