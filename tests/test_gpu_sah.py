@@ -149,3 +149,34 @@ def test_root_table_octant_variants_same_image(hip_lib, oracle_lib):
     c.render(1, 1, 1, 1, 2, 0)
     assert c.info()["root_table_variants"] == 1
     c.close()
+
+
+@pytest.mark.gpu
+def test_vote_at_the_extremes_of_the_refill_threshold(hip_lib, oracle_lib):
+    """The traversal loop has ONE way out: fewer than refill_below lanes traverse and some lane waits for the path block (round 3: the
+    vote written for the scalar unit).  At the ends of the range - 1: a wave shades only when nobody traverses; 64: as soon as one lane
+    has finished - and for every burst length the image must still be the oracle's, in the exact mode and with both structures culled."""
+    w, h = 160, 90
+    sc = build_suzanne(0)
+    o = oracle_lib.create()
+    o.load_scene(sc)
+    o.load_camera(sc.cam)
+    o.resize(w, h)
+    o.render(1, 3, 1, 2, 5, 0)
+    want = o.read_mean().view(np.uint32)
+    old = {k: os.environ.get(k) for k in ("RT_REFILL_BELOW", "RT_BURST8")}
+    try:
+        for refill, burst in (("1", "3"), ("64", "3"), ("2", "0"), ("63", "8"), ("22", "64")):
+            os.environ["RT_REFILL_BELOW"], os.environ["RT_BURST8"] = refill, burst      # read by rt_create
+            for sah, cull in ((False, 0), (False, 1), (True, 1)):
+                c = _ctx(hip_lib, build_suzanne(0), w, h, sah, cull)
+                c.render(1, 3, 1, 2, 5, 0)
+                got = c.read_mean().view(np.uint32)
+                c.close()
+                assert np.array_equal(got, want), f"refill {refill}, burst {burst}, sah {sah}, cull {cull}"
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
